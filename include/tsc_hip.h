@@ -1,0 +1,148 @@
+/*
+ * tsc_hip.h -- C-ABI of libtsc_hip.so, the MI355X (gfx950) backend of the feature-activation
+ * hot path of charlieoneill11/transcoder-sae-circuits.
+ *
+ * The reference has no FFI: the path sits behind Python methods.  Each
+ * entry point below names the reference code it replaces (paths under the reference's src/).
+ * Conventions:
+ *   - every pointer marked "device" is a HIP device pointer owned by the caller (in practice a
+ *     torch tensor's data_ptr()); the library never returns memory the caller must free except
+ *     the opaque dictionary handle (tsc_dict_destroy);
+ *   - all tensors are dense row-major; fp32 unless said otherwise; token ids are int64;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and
+ *     the call returns without synchronising;
+ *   - return value 0 = ok, negative = error (tsc_last_error() gives the thread's message);
+ *     nothing throws across the boundary.
+ */
+#ifndef TSC_HIP_H
+#define TSC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSC_OK 0
+#define TSC_ERR_ARG (-1)         /* bad shape / null pointer / misaligned pointer            */
+#define TSC_ERR_HIP (-2)         /* a HIP runtime call failed                                */
+#define TSC_ERR_UNSUPPORTED (-3) /* shape outside what the kernels are built for             */
+
+#define TSC_F32 0  /* fp32 inputs/weights, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)            */
+#define TSC_BF16 1 /* bf16-rounded inputs/weights, fp32 accumulate (v_mfma_f32_32x32x16_bf16)  */
+
+typedef struct tsc_dict tsc_dict_t; /* opaque: one transcoder or z-SAE resident on one GPU */
+typedef void *tsc_stream_t;         /* hipStream_t */
+
+/* Library version (major*100+minor) and the last error text of the calling thread. */
+int tsc_version(void);
+const char *tsc_last_error(void);
+
+/*
+ * Register one dictionary.  Replaces the parameter set of SparseTranscoder.__init__
+ * (mlp_transcoder.py:70-99) / ZSAE.__init__ (z_sae.py:34-47).  Pointers are BORROWED and must
+ * outlive the handle: W_enc [d_in,d_sae], b_enc [d_sae], b_dec [d_in], W_dec [d_sae,d_out],
+ * out_bias [d_out] (= b_dec_out for a transcoder, = b_dec for a z-SAE; mlp_transcoder.py:131-147,
+ * z_sae.py:62).  W_dec/out_bias may be NULL if only encode entry points are used.
+ * compute_dtype TSC_BF16 makes one device-side bf16 copy of W_enc (hipMalloc, freed by destroy).
+ * Requires d_in % 4 == 0 and d_sae % 4 == 0, 16-byte aligned pointers.
+ */
+int tsc_dict_create(tsc_dict_t **out, int d_in, int d_sae, int d_out, int compute_dtype,
+                    const float *W_enc, const float *b_enc, const float *b_dec,
+                    const float *W_dec, const float *out_bias, tsc_stream_t stream);
+int tsc_dict_destroy(tsc_dict_t *dict);
+
+/*
+ * out[M,d_sae] = relu((x[M,d_in] - b_dec) @ W_enc + b_enc).
+ * Replaces SparseTranscoder.encode (mlp_transcoder.py:194-213) and ZSAE.encode (z_sae.py:73-77).
+ */
+int tsc_encode_dense(const tsc_dict_t *dict, const float *x, int64_t M, float *out,
+                     tsc_stream_t stream);
+
+/*
+ * Running per-feature top-k of max-activating tokens.  The state is caller-owned device memory:
+ *   vals [n_slots, d_sae, k] fp32 and idx [n_slots, d_sae, k] int64.
+ * A "slot" is an independent partial list set; the encode kernel splits each batch's token tiles
+ * over n_slots groups of workgroups so that no two workgroups ever touch one list, and
+ * tsc_topk_finalize merges the slots.  tsc_topk_recommended_slots(d_sae) returns the slot count
+ * that fills the chip evenly (any n_slots >= 1 is correct).
+ */
+typedef struct {
+    float *vals;   /* device */
+    int64_t *idx;  /* device */
+    int32_t d_sae;
+    int32_t k;       /* 1..64 */
+    int32_t n_slots; /* 1..64 */
+} tsc_topk_state_t;
+
+int tsc_topk_recommended_slots(int d_sae);
+/* Fill every list with the padding entry (0.0, -1). */
+int tsc_topk_state_reset(const tsc_topk_state_t *state, tsc_stream_t stream);
+
+/*
+ * Fused encode + top-k insert for tokens token_id_base .. token_id_base+M-1: the [M,d_sae]
+ * activation matrix is never written.  Only activations > 0 are candidates; ranking is value
+ * descending then token id ascending.  Replaces the loop body of MaxActAnalysis.active_examples
+ * (max_act_analysis.py:215-249: encode, [:, feature], .cpu(), concat, argsort) for ALL features
+ * at once, and the dense dump of max_activating.py:41-65,117-120.
+ */
+int tsc_encode_topk(const tsc_dict_t *dict, const float *x, int64_t M, int64_t token_id_base,
+                    const tsc_topk_state_t *state, tsc_stream_t stream);
+
+/*
+ * Merge n_lists list sets laid out [n_lists, d_sae, k] into out_vals/out_idx [d_sae, k], sorted
+ * (value desc, token id asc), short lists padded with (0.0, -1).  n_lists * k <= 2048.
+ * tsc_topk_finalize = merge of the state's slots.  tsc_topk_merge is also the step after the
+ * RCCL all-gather of per-rank lists (no reference counterpart: the reference is single-process,
+ * SURVEY.md section 2.2).  out may not alias the inputs.
+ */
+int tsc_topk_merge(const float *vals, const int64_t *idx, int n_lists, int d_sae, int k,
+                   float *out_vals, int64_t *out_idx, tsc_stream_t stream);
+int tsc_topk_finalize(const tsc_topk_state_t *state, float *out_vals, int64_t *out_idx,
+                      tsc_stream_t stream);
+
+/*
+ * Sparse emit: for every token row m, the active features (act > 0) sorted by value descending
+ * (ties: feature id ascending): feat[m, 0..count[m]) int32, val[m, 0..count[m]) fp32, with row
+ * pitch max_active (<= 8192).  count[m] is the TRUE number of active features; if it exceeds
+ * max_active only max_active arbitrary ones were kept and the caller must retry with a larger
+ * capacity.  Replaces `nonzero().numel()` + `topk(k=count)` of CircuitLens.get_active_features
+ * (circuit_lens.py:612-614, 647-649) for a whole batch of positions.
+ */
+int tsc_encode_sparse(const tsc_dict_t *dict, const float *x, int64_t M, int max_active,
+                      int32_t *feat, float *val, int32_t *count, tsc_stream_t stream);
+
+/*
+ * rows[i, :] = val[i] * W_dec[feat[i], :] for i < n.  Replaces `W_dec[idx] * vals.unsqueeze(-1)`
+ * (circuit_lens.py:616, 651-653, 1220-1222).
+ */
+int tsc_decode_rows(const tsc_dict_t *dict, const int32_t *feat, const float *val, int64_t n,
+                    float *rows, tsc_stream_t stream);
+
+/*
+ * recon[m, :] = out_bias + sum_i val[m,i] * W_dec[feat[m,i], :], i < min(count[m], max_active).
+ * Replaces the decoder half of SparseTranscoder.forward (mlp_transcoder.py:128-147) and
+ * ZSAE.forward (z_sae.py:62) on the sparse form.
+ */
+int tsc_decode_sparse(const tsc_dict_t *dict, const int32_t *feat, const float *val,
+                      const int32_t *count, int64_t M, int max_active, float *recon,
+                      tsc_stream_t stream);
+
+/*
+ * Contribution scores, the north star's `feature_act x W_dec row . target direction`:
+ *   scores[m, i, d] = val[m,i] * dot(W_dec[feat[m,i], :], dirs[d, :]),  i < min(count[m], max_active),
+ * dirs [n_dir, d_out], n_dir <= 8.  Entries at i >= count[m] are written as 0.
+ * Replaces the einsum of the lens functions on feature rows (circuit_lens.py:762-766, 955-957)
+ * and get_transcoder_ixg (circuit_lens.py:1151-1164) restricted to the active features.  For an
+ * attention dictionary pass dirs' = W_O[layer] (as [d_out, d_model]) @ dir, which folds the W_O
+ * projection of circuit_lens.py:618-627 into the direction.
+ */
+int tsc_contrib_scores(const tsc_dict_t *dict, const int32_t *feat, const float *val,
+                       const int32_t *count, int64_t M, int max_active, const float *dirs,
+                       int n_dir, float *scores, tsc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSC_HIP_H */

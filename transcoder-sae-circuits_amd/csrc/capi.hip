@@ -1,0 +1,240 @@
+// extern "C" surface of libtsc_hip.so (declared in include/tsc_hip.h): argument checking, the
+// dictionary handle, and the choice of launch geometry.  No torch types, no exceptions.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "tsc_internal.h"
+
+static thread_local char g_err[512] = "";
+
+int tsc_fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+namespace {
+
+constexpr int TILE_N = 128, TILE_M = 128;
+constexpr int RESIDENT_WGS = 512;  // 256 CUs x 2 workgroups (LDS-limited)
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// number of token-tile groups per column tile such that the grid is a whole number of waves of
+// resident workgroups (every workgroup does the same amount of work, so a ragged last wave of
+// workgroups is pure idle time)
+int balanced_split(int n_tiles_n, long long n_tiles_m, int cap) {
+    if (cap > n_tiles_m) cap = (int)(n_tiles_m < 1 ? 1 : n_tiles_m);
+    for (int s = 1; s <= cap; ++s)
+        if (((long long)n_tiles_n * s) % RESIDENT_WGS == 0) return s;
+    int s = (2 * RESIDENT_WGS + n_tiles_n - 1) / n_tiles_n;
+    if (s < 1) s = 1;
+    return s > cap ? cap : s;
+}
+
+int check_dict_x(const tsc_dict_t *d, const float *x, int64_t M) {
+    if (!d) return tsc_fail(TSC_ERR_ARG, "null dictionary handle");
+    if (M < 0) return tsc_fail(TSC_ERR_ARG, "negative row count %lld", (long long)M);
+    if (M > 0 && !x) return tsc_fail(TSC_ERR_ARG, "null activation pointer");
+    if (!aligned16(x)) return tsc_fail(TSC_ERR_ARG, "activation pointer not 16-byte aligned");
+    return TSC_OK;
+}
+
+EncodeArgs base_args(const tsc_dict_t *d, const float *x, int64_t M) {
+    EncodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.W = d->W_enc; a.b_enc = d->b_enc; a.b_dec = d->b_dec;
+    a.M = M; a.K = d->d_in; a.N = d->d_sae;
+    a.n_tiles_n = (d->d_sae + TILE_N - 1) / TILE_N;
+    a.m_split = 1;
+    return a;
+}
+
+int run_encode(const tsc_dict_t *d, int mode, const EncodeArgs &a, hipStream_t s) {
+    if (d->compute_dtype == TSC_BF16) return tsc_launch_encode_bf16(mode, a, d->W_enc_bf16, s);
+    return tsc_launch_encode_f32(mode, a, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsc_version(void) { return 100; }
+const char *tsc_last_error(void) { return g_err; }
+
+int tsc_dict_create(tsc_dict_t **out, int d_in, int d_sae, int d_out, int compute_dtype,
+                    const float *W_enc, const float *b_enc, const float *b_dec, const float *W_dec,
+                    const float *out_bias, tsc_stream_t stream) {
+    if (!out) return tsc_fail(TSC_ERR_ARG, "null output handle");
+    *out = nullptr;
+    if (d_in <= 0 || d_sae <= 0 || d_out <= 0) return tsc_fail(TSC_ERR_ARG, "non-positive dimension");
+    if ((d_in & 3) || (d_sae & 3) || (d_out & 3))
+        return tsc_fail(TSC_ERR_UNSUPPORTED, "d_in, d_sae and d_out must be multiples of 4 (got %d, %d, %d)",
+                        d_in, d_sae, d_out);
+    if (!W_enc || !b_enc || !b_dec) return tsc_fail(TSC_ERR_ARG, "W_enc, b_enc and b_dec are required");
+    if (!aligned16(W_enc) || !aligned16(b_dec) || !aligned16(W_dec) || !aligned16(out_bias))
+        return tsc_fail(TSC_ERR_ARG, "weight pointers must be 16-byte aligned");
+    if (compute_dtype != TSC_F32 && compute_dtype != TSC_BF16)
+        return tsc_fail(TSC_ERR_ARG, "unknown compute dtype %d", compute_dtype);
+    tsc_dict *d = new (std::nothrow) tsc_dict;
+    if (!d) return tsc_fail(TSC_ERR_HIP, "out of host memory");
+    memset(d, 0, sizeof(*d));
+    d->d_in = d_in; d->d_sae = d_sae; d->d_out = d_out; d->compute_dtype = compute_dtype;
+    d->W_enc = W_enc; d->b_enc = b_enc; d->b_dec = b_dec; d->W_dec = W_dec; d->out_bias = out_bias;
+    if (compute_dtype == TSC_BF16) {
+        if ((d_in & 31) || (d_sae & 127)) {
+            delete d;
+            return tsc_fail(TSC_ERR_UNSUPPORTED, "bf16 path needs d_in %% 32 == 0 and d_sae %% 128 == 0");
+        }
+        hipError_t e = hipMalloc(&d->W_enc_bf16, (size_t)d_in * d_sae * 2);
+        if (e != hipSuccess) {
+            delete d;
+            return tsc_fail(TSC_ERR_HIP, "hipMalloc of the bf16 W_enc copy failed: %s", hipGetErrorString(e));
+        }
+        int rc = tsc_pack_w_bf16(W_enc, d_in, d_sae, d->W_enc_bf16, (hipStream_t)stream);
+        if (rc != TSC_OK) {
+            (void)hipFree(d->W_enc_bf16);
+            delete d;
+            return rc;
+        }
+    }
+    *out = d;
+    return TSC_OK;
+}
+
+int tsc_dict_destroy(tsc_dict_t *d) {
+    if (!d) return TSC_OK;
+    if (d->W_enc_bf16) (void)hipFree(d->W_enc_bf16);
+    delete d;
+    return TSC_OK;
+}
+
+int tsc_encode_dense(const tsc_dict_t *d, const float *x, int64_t M, float *out, tsc_stream_t stream) {
+    int rc = check_dict_x(d, x, M);
+    if (rc) return rc;
+    if (M == 0) return TSC_OK;
+    if (!out) return tsc_fail(TSC_ERR_ARG, "null output pointer");
+    EncodeArgs a = base_args(d, x, M);
+    a.out = out;
+    a.m_split = balanced_split(a.n_tiles_n, (M + TILE_M - 1) / TILE_M, 64);
+    return run_encode(d, TSC_MODE_DENSE, a, (hipStream_t)stream);
+}
+
+int tsc_topk_recommended_slots(int d_sae) {
+    if (d_sae <= 0) return 1;
+    return balanced_split((d_sae + TILE_N - 1) / TILE_N, 1 << 30, 16);
+}
+
+static int check_state(const tsc_topk_state_t *s) {
+    if (!s || !s->vals || !s->idx) return tsc_fail(TSC_ERR_ARG, "null top-k state");
+    if (s->d_sae <= 0 || s->k < 1 || s->k > 64 || s->n_slots < 1 || s->n_slots > 64)
+        return tsc_fail(TSC_ERR_ARG, "top-k state out of range (d_sae %d, k %d, n_slots %d)", s->d_sae, s->k,
+                        s->n_slots);
+    return TSC_OK;
+}
+
+int tsc_topk_state_reset(const tsc_topk_state_t *s, tsc_stream_t stream) {
+    int rc = check_state(s);
+    if (rc) return rc;
+    return tsc_launch_topk_fill(s->vals, (long long *)s->idx, (long long)s->n_slots * s->d_sae * s->k,
+                                (hipStream_t)stream);
+}
+
+int tsc_encode_topk(const tsc_dict_t *d, const float *x, int64_t M, int64_t token_id_base,
+                    const tsc_topk_state_t *s, tsc_stream_t stream) {
+    int rc = check_dict_x(d, x, M);
+    if (rc) return rc;
+    rc = check_state(s);
+    if (rc) return rc;
+    if (s->d_sae != d->d_sae)
+        return tsc_fail(TSC_ERR_ARG, "state d_sae %d does not match dictionary d_sae %d", s->d_sae, d->d_sae);
+    if (token_id_base < 0) return tsc_fail(TSC_ERR_ARG, "negative token id base");
+    if (M == 0) return TSC_OK;
+    EncodeArgs a = base_args(d, x, M);
+    a.tk_vals = s->vals;
+    a.tk_idx = (long long *)s->idx;
+    a.topk = s->k;
+    a.token_base = token_id_base;
+    a.m_split = s->n_slots;
+    return run_encode(d, TSC_MODE_TOPK, a, (hipStream_t)stream);
+}
+
+int tsc_topk_merge(const float *vals, const int64_t *idx, int n_lists, int d_sae, int k, float *out_vals,
+                   int64_t *out_idx, tsc_stream_t stream) {
+    if (!vals || !idx || !out_vals || !out_idx) return tsc_fail(TSC_ERR_ARG, "null list pointer");
+    if (n_lists < 1 || d_sae < 1 || k < 1) return tsc_fail(TSC_ERR_ARG, "non-positive merge dimension");
+    if (out_vals == vals || (const int64_t *)out_idx == idx)
+        return tsc_fail(TSC_ERR_ARG, "merge output may not alias its input");
+    return tsc_launch_topk_merge(vals, (const long long *)idx, n_lists, d_sae, k, out_vals,
+                                 (long long *)out_idx, (hipStream_t)stream);
+}
+
+int tsc_topk_finalize(const tsc_topk_state_t *s, float *out_vals, int64_t *out_idx, tsc_stream_t stream) {
+    int rc = check_state(s);
+    if (rc) return rc;
+    return tsc_topk_merge(s->vals, s->idx, s->n_slots, s->d_sae, s->k, out_vals, out_idx, stream);
+}
+
+int tsc_encode_sparse(const tsc_dict_t *d, const float *x, int64_t M, int max_active, int32_t *feat,
+                      float *val, int32_t *count, tsc_stream_t stream) {
+    int rc = check_dict_x(d, x, M);
+    if (rc) return rc;
+    if (M == 0) return TSC_OK;
+    if (!feat || !val || !count) return tsc_fail(TSC_ERR_ARG, "null sparse output pointer");
+    if (max_active < 1 || max_active > 8192) return tsc_fail(TSC_ERR_ARG, "max_active %d outside 1..8192", max_active);
+    hipStream_t s = (hipStream_t)stream;
+    TSC_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)M * sizeof(int32_t), s));
+    EncodeArgs a = base_args(d, x, M);
+    a.sp_feat = feat; a.sp_val = val; a.sp_count = count; a.max_active = max_active;
+    a.m_split = balanced_split(a.n_tiles_n, (M + TILE_M - 1) / TILE_M, 64);
+    rc = run_encode(d, TSC_MODE_SPARSE, a, s);
+    if (rc) return rc;
+    return tsc_launch_sparse_sort(feat, val, count, M, max_active, s);
+}
+
+static int check_decoder(const tsc_dict_t *d) {
+    if (!d) return tsc_fail(TSC_ERR_ARG, "null dictionary handle");
+    if (!d->W_dec) return tsc_fail(TSC_ERR_ARG, "dictionary was created without W_dec");
+    return TSC_OK;
+}
+
+int tsc_decode_rows(const tsc_dict_t *d, const int32_t *feat, const float *val, int64_t n, float *rows,
+                    tsc_stream_t stream) {
+    int rc = check_decoder(d);
+    if (rc) return rc;
+    if (n < 0) return tsc_fail(TSC_ERR_ARG, "negative row count");
+    if (n == 0) return TSC_OK;
+    if (!feat || !val || !rows || !aligned16(rows)) return tsc_fail(TSC_ERR_ARG, "bad decode_rows pointer");
+    return tsc_launch_decode_rows(d->W_dec, d->d_out, feat, val, n, rows, (hipStream_t)stream);
+}
+
+int tsc_decode_sparse(const tsc_dict_t *d, const int32_t *feat, const float *val, const int32_t *count,
+                      int64_t M, int max_active, float *recon, tsc_stream_t stream) {
+    int rc = check_decoder(d);
+    if (rc) return rc;
+    if (M < 0 || max_active < 1) return tsc_fail(TSC_ERR_ARG, "bad decode_sparse shape");
+    if (M == 0) return TSC_OK;
+    if (!feat || !val || !count || !recon || !aligned16(recon))
+        return tsc_fail(TSC_ERR_ARG, "bad decode_sparse pointer");
+    return tsc_launch_decode_sparse(d->W_dec, d->out_bias, d->d_out, feat, val, count, M, max_active, recon,
+                                    (hipStream_t)stream);
+}
+
+int tsc_contrib_scores(const tsc_dict_t *d, const int32_t *feat, const float *val, const int32_t *count,
+                       int64_t M, int max_active, const float *dirs, int n_dir, float *scores,
+                       tsc_stream_t stream) {
+    int rc = check_decoder(d);
+    if (rc) return rc;
+    if (M < 0 || max_active < 1) return tsc_fail(TSC_ERR_ARG, "bad contrib_scores shape");
+    if (M == 0) return TSC_OK;
+    if (!feat || !val || !count || !dirs || !scores || !aligned16(dirs))
+        return tsc_fail(TSC_ERR_ARG, "bad contrib_scores pointer");
+    return tsc_launch_contrib(d->W_dec, d->d_out, feat, val, count, M, max_active, dirs, n_dir, scores,
+                              (hipStream_t)stream);
+}
+
+}  // extern "C"

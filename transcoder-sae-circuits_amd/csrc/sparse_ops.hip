@@ -1,0 +1,223 @@
+// Sparse-feature kernels of the CircuitLens contribution pass.  All are HBM-bound gathers of
+// coalesced W_dec rows (d_out * 4 = 3072 bytes each for GPT-2 small); none is reshaped into a GEMM.
+//
+//   sparse_sort    : per token, order the (feature, value) pairs emitted by the SPARSE encode
+//                    epilogue by value descending -- `topk(k=count)` of reference
+//                    src/circuit_lens.py:612-614 / 647-649.
+//   decode_rows    : rows[i] = val[i] * W_dec[feat[i]]          (circuit_lens.py:616, 651-653)
+//   decode_sparse  : recon[m] = bias + sum_i val * W_dec[feat]  (mlp_transcoder.py:128-147, z_sae.py:62)
+//   contrib        : scores[m,i,d] = val * dot(W_dec[feat], dirs[d])  (circuit_lens.py:762-766,
+//                    955-957, 1151-1164 restricted to active features)
+#include "tsc_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SORT_MAX = 8192;
+constexpr int DIR_MAX = 8;
+
+// grid = M, block = 256.  Rank sort in LDS: rank(e) = #entries that precede e.
+__global__ __launch_bounds__(256) void sparse_sort_kernel(int *feat, float *val, const int *count,
+                                                         int max_active) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *sv = (float *)smem_raw;
+    int *sf = (int *)(smem_raw + sizeof(float) * max_active);
+    const long long m = blockIdx.x;
+    int c = count[m];
+    if (c > max_active) c = max_active;
+    int *frow = feat + m * max_active;
+    float *vrow = val + m * max_active;
+    for (int e = threadIdx.x; e < c; e += blockDim.x) {
+        sv[e] = vrow[e];
+        sf[e] = frow[e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < c; e += blockDim.x) {
+        const float v = sv[e];
+        const int f = sf[e];
+        int rank = 0;
+        for (int j = 0; j < c; ++j) {
+            const float w = sv[j];
+            rank += (w > v || (w == v && sf[j] < f)) ? 1 : 0;
+        }
+        vrow[rank] = v;
+        frow[rank] = f;
+    }
+    // zero the unused tail so the buffers are fully defined
+    for (int e = c + threadIdx.x; e < max_active; e += blockDim.x) {
+        vrow[e] = 0.f;
+        frow[e] = -1;
+    }
+}
+
+// one wavefront per row; each lane moves float4 chunks
+__global__ __launch_bounds__(256) void decode_rows_kernel(const float *W_dec, int d_out, const int *feat,
+                                                         const float *val, long long n, float *rows) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int chunks = d_out >> 2;
+    for (long long i = wave; i < n; i += n_waves) {
+        const int f = feat[i];
+        const float v = val[i];
+        const f32x4 *src = (const f32x4 *)(W_dec + (long long)f * d_out);
+        f32x4 *dst = (f32x4 *)(rows + i * d_out);
+        for (int c = lane; c < chunks; c += 64) dst[c] = src[c] * v;
+    }
+}
+
+// grid = M; each thread owns float4 column chunks and walks the token's active list
+__global__ __launch_bounds__(256) void decode_sparse_kernel(const float *W_dec, const float *bias, int d_out,
+                                                           const int *feat, const float *val,
+                                                           const int *count, int max_active, float *recon) {
+    __shared__ int sf[256];
+    __shared__ float sv[256];
+    const long long m = blockIdx.x;
+    int c = count[m];
+    if (c > max_active) c = max_active;
+    const int chunks = d_out >> 2;
+    // up to 4 chunks per thread (d_out <= 4096)
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < c; base += 256) {
+        const int nb = c - base < 256 ? c - base : 256;
+        __syncthreads();
+        if ((int)threadIdx.x < nb) {
+            sf[threadIdx.x] = feat[m * max_active + base + threadIdx.x];
+            sv[threadIdx.x] = val[m * max_active + base + threadIdx.x];
+        }
+        __syncthreads();
+        for (int e = 0; e < nb; ++e) {
+            const f32x4 *src = (const f32x4 *)(W_dec + (long long)sf[e] * d_out);
+            const float v = sv[e];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = threadIdx.x + 256 * j;
+                if (ch < chunks) acc[j] += src[ch] * v;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ch = threadIdx.x + 256 * j;
+        if (ch < chunks) {
+            f32x4 b = bias ? ((const f32x4 *)bias)[ch] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            ((f32x4 *)(recon + m * d_out))[ch] = acc[j] + b;
+        }
+    }
+}
+
+// one wavefront per (token, active slot) pair; directions staged in LDS once per block
+template <int NDIR>
+__global__ __launch_bounds__(256) void contrib_kernel(const float *W_dec, int d_out, const int *feat,
+                                                     const float *val, const int *count, long long M,
+                                                     int max_active, const float *dirs, float *scores) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4 *sd = (f32x4 *)smem_raw;  // [NDIR][d_out/4]
+    const int chunks = d_out >> 2;
+    for (int i = threadIdx.x; i < NDIR * chunks; i += blockDim.x) sd[i] = ((const f32x4 *)dirs)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long total = M * max_active;
+    for (long long p = wave; p < total; p += n_waves) {
+        const long long m = p / max_active;
+        const int i = (int)(p - m * max_active);
+        int c = count[m];
+        if (c > max_active) c = max_active;
+        float part[NDIR];
+#pragma unroll
+        for (int d = 0; d < NDIR; ++d) part[d] = 0.f;
+        float v = 0.f;
+        if (i < c) {  // wave-uniform
+            v = val[p];
+            const f32x4 *src = (const f32x4 *)(W_dec + (long long)feat[p] * d_out);
+            for (int ch = lane; ch < chunks; ch += 64) {
+                const f32x4 w = src[ch];
+#pragma unroll
+                for (int d = 0; d < NDIR; ++d) {
+                    const f32x4 q = sd[d * chunks + ch];
+                    part[d] += w.x * q.x + w.y * q.y + w.z * q.z + w.w * q.w;
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < NDIR; ++d)
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) part[d] += __shfl_xor(part[d], off);
+        }
+        if (lane < NDIR) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < NDIR; ++d) s = lane == d ? part[d] : s;
+            scores[p * NDIR + lane] = s * v;
+        }
+    }
+}
+
+template <int NDIR>
+int launch_contrib(const float *W_dec, int d_out, const int *feat, const float *val, const int *count,
+                   long long M, int max_active, const float *dirs, float *scores, hipStream_t stream) {
+    const long long pairs = M * max_active;
+    long long blocks = (pairs + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    const size_t lds = (size_t)NDIR * d_out * sizeof(float);
+    hipLaunchKernelGGL(contrib_kernel<NDIR>, dim3((unsigned)blocks), dim3(256), lds, stream, W_dec, d_out,
+                       feat, val, count, M, max_active, dirs, scores);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
+}  // namespace
+
+int tsc_launch_sparse_sort(int *feat, float *val, const int *count, long long M, int max_active,
+                           hipStream_t stream) {
+    if (M <= 0) return TSC_OK;
+    if (max_active > SORT_MAX)
+        return tsc_fail(TSC_ERR_UNSUPPORTED, "max_active %d exceeds %d", max_active, SORT_MAX);
+    const size_t lds = (size_t)max_active * 8;
+    hipLaunchKernelGGL(sparse_sort_kernel, dim3((unsigned)M), dim3(256), lds, stream, feat, val, count,
+                       max_active);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
+int tsc_launch_decode_rows(const float *W_dec, int d_out, const int *feat, const float *val, long long n,
+                           float *rows, hipStream_t stream) {
+    if (n <= 0) return TSC_OK;
+    long long blocks = (n + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(decode_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, W_dec, d_out, feat,
+                       val, n, rows);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
+int tsc_launch_decode_sparse(const float *W_dec, const float *bias, int d_out, const int *feat,
+                             const float *val, const int *count, long long M, int max_active, float *recon,
+                             hipStream_t stream) {
+    if (M <= 0) return TSC_OK;
+    if (d_out > 4096) return tsc_fail(TSC_ERR_UNSUPPORTED, "d_out %d exceeds 4096", d_out);
+    hipLaunchKernelGGL(decode_sparse_kernel, dim3((unsigned)M), dim3(256), 0, stream, W_dec, bias, d_out,
+                       feat, val, count, max_active, recon);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
+int tsc_launch_contrib(const float *W_dec, int d_out, const int *feat, const float *val, const int *count,
+                       long long M, int max_active, const float *dirs, int n_dir, float *scores,
+                       hipStream_t stream) {
+    if (M <= 0) return TSC_OK;
+    if (n_dir < 1 || n_dir > DIR_MAX) return tsc_fail(TSC_ERR_ARG, "n_dir %d outside 1..%d", n_dir, DIR_MAX);
+    if ((size_t)n_dir * d_out * 4 > 60 * 1024)
+        return tsc_fail(TSC_ERR_UNSUPPORTED, "n_dir * d_out too large for the LDS staging");
+#define TSC_CASE(N) \
+    case N: return launch_contrib<N>(W_dec, d_out, feat, val, count, M, max_active, dirs, scores, stream);
+    switch (n_dir) {
+        TSC_CASE(1) TSC_CASE(2) TSC_CASE(3) TSC_CASE(4) TSC_CASE(5) TSC_CASE(6) TSC_CASE(7) TSC_CASE(8)
+    }
+#undef TSC_CASE
+    return TSC_ERR_ARG;
+}

@@ -1,0 +1,93 @@
+// Per-feature top-k list maintenance outside the encode kernel: reset, and the k-way merge used
+// both to fold the encode kernel's slots into the final lists and to combine the lists of several
+// ranks after the RCCL all-gather.  There is no reference counterpart beyond
+// `argsort(descending=True)[:num_active]` (reference src/max_act_analysis.py:245-249), whose
+// result these kernels reproduce with the tie rule "equal values: smaller token id first".
+// HBM-bound integer/compare work; one wavefront per feature.
+#include "tsc_internal.h"
+
+namespace {
+
+constexpr int MERGE_MAX = 2048;  // n_lists * k entries staged in LDS per feature
+
+__global__ void topk_fill_kernel(float *vals, long long *idx, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        vals[i] = 0.f;
+        idx[i] = -1;
+    }
+}
+
+__device__ __forceinline__ bool ranks_above(float v, long long id, float w, long long wid) {
+    return v > w || (v == w && id < wid);
+}
+
+// grid = d_sae, block = 64.  Entries with id < 0 or value <= 0 are padding.
+__global__ __launch_bounds__(64) void topk_merge_kernel(const float *vals, const long long *idx,
+                                                        int n_lists, int d_sae, int k,
+                                                        float *out_vals, long long *out_idx) {
+    __shared__ float sv[MERGE_MAX];
+    __shared__ long long sid[MERGE_MAX];
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int total = n_lists * k;
+    for (int e = lane; e < total; e += 64) {
+        const int l = e / k, i = e - l * k;
+        const long long off = ((long long)l * d_sae + f) * k + i;
+        const long long id = idx[off];
+        const float v = vals[off];
+        const bool live = id >= 0 && v > 0.f;
+        sv[e] = live ? v : -1.f;
+        sid[e] = live ? id : -1;
+    }
+    __syncthreads();
+    for (int round = 0; round < k; ++round) {
+        float bv = -1.f;
+        long long bid = -1;
+        int be = -1;
+        for (int e = lane; e < total; e += 64) {
+            const float v = sv[e];
+            if (v > 0.f && (be < 0 || ranks_above(v, sid[e], bv, bid))) {
+                bv = v; bid = sid[e]; be = e;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const long long oid = __shfl_xor(bid, off);
+            const int oe = __shfl_xor(be, off);
+            // identical (value, id) pairs can come from two lists (the same token seen twice):
+            // break that tie by entry index so every lane agrees on one winner
+            const bool take = oe >= 0 && (be < 0 || ranks_above(ov, oid, bv, bid) ||
+                                          (ov == bv && oid == bid && oe < be));
+            if (take) { bv = ov; bid = oid; be = oe; }
+        }
+        if (lane == 0) {
+            out_vals[(long long)f * k + round] = be >= 0 ? bv : 0.f;
+            out_idx[(long long)f * k + round] = be >= 0 ? bid : -1;
+            if (be >= 0) sv[be] = -1.f;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+int tsc_launch_topk_fill(float *vals, long long *idx, long long n, hipStream_t stream) {
+    if (n <= 0) return TSC_OK;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(topk_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, vals, idx, n);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
+int tsc_launch_topk_merge(const float *vals, const long long *idx, int n_lists, int d_sae, int k,
+                          float *out_vals, long long *out_idx, hipStream_t stream) {
+    if ((long long)n_lists * k > MERGE_MAX)
+        return tsc_fail(TSC_ERR_UNSUPPORTED, "merge of %d lists x k=%d exceeds %d entries per feature",
+                        n_lists, k, MERGE_MAX);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)d_sae), dim3(64), 0, stream, vals, idx,
+                       n_lists, d_sae, k, out_vals, out_idx);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}

@@ -1,0 +1,62 @@
+// Internal declarations shared by the HIP translation units of libtsc_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tsc_hip.h"
+
+struct tsc_dict {
+    int d_in, d_sae, d_out, compute_dtype;
+    const float *W_enc, *b_enc, *b_dec, *W_dec, *out_bias;  // borrowed, device
+    void *W_enc_bf16;                                       // owned (TSC_BF16 only): [d_sae/32][d_in/8][32][8] bf16
+    void *b_dec_dummy;
+};
+
+// error plumbing (capi.hip)
+int tsc_fail(int code, const char *fmt, ...);
+#define TSC_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return tsc_fail(TSC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                            __FILE__, __LINE__);                                             \
+    } while (0)
+
+// encode_f32.hip
+enum { TSC_MODE_DENSE = 0, TSC_MODE_TOPK = 1, TSC_MODE_SPARSE = 2 };
+struct EncodeArgs {
+    const float *x, *W, *b_enc, *b_dec;
+    long long M;
+    int K, N;
+    int n_tiles_n, m_split;
+    float *out;          // DENSE
+    float *tk_vals;      // TOPK: [m_split][N][topk]
+    long long *tk_idx;   //
+    int topk;
+    long long token_base;
+    int *sp_feat;        // SPARSE: [M][max_active]
+    float *sp_val;
+    int *sp_count;       // [M], zeroed by the caller
+    int max_active;
+};
+int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream);
+int tsc_launch_encode_bf16(int mode, const EncodeArgs &a, const void *W_bf16, hipStream_t stream);
+int tsc_pack_w_bf16(const float *W, int K, int N, void *dst, hipStream_t stream);
+
+// topk_merge.hip
+int tsc_launch_topk_fill(float *vals, long long *idx, long long n, hipStream_t stream);
+int tsc_launch_topk_merge(const float *vals, const long long *idx, int n_lists, int d_sae, int k,
+                          float *out_vals, long long *out_idx, hipStream_t stream);
+
+// sparse_ops.hip
+int tsc_launch_sparse_sort(int *feat, float *val, const int *count, long long M, int max_active,
+                           hipStream_t stream);
+int tsc_launch_decode_rows(const float *W_dec, int d_out, const int *feat, const float *val,
+                           long long n, float *rows, hipStream_t stream);
+int tsc_launch_decode_sparse(const float *W_dec, const float *bias, int d_out, const int *feat,
+                             const float *val, const int *count, long long M, int max_active,
+                             float *recon, hipStream_t stream);
+int tsc_launch_contrib(const float *W_dec, int d_out, const int *feat, const float *val,
+                       const int *count, long long M, int max_active, const float *dirs, int n_dir,
+                       float *scores, hipStream_t stream);

@@ -1,0 +1,249 @@
+"""ctypes binding of ``libtsc_hip.so`` (C-ABI in ``include/tsc_hip.h``) for torch-ROCm tensors.
+
+torch is plumbing here: it owns device memory and the HIP stream.  Every function passes raw
+``data_ptr()`` values and ``torch.cuda.current_stream().cuda_stream`` across the C boundary.
+There is NO fallback: if the library is not built, or a tensor is not on a GPU, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtsc_hip.so")
+_lib: Optional[ctypes.CDLL] = None
+
+F32, BF16 = 0, 1
+MAX_ACTIVE_LIMIT = 8192
+MAX_DIRS = 8
+
+# name -> (restype, argtypes); mirrors include/tsc_hip.h one to one
+_c = ctypes
+_SIGNATURES = {
+    "tsc_version": (_c.c_int, []),
+    "tsc_last_error": (_c.c_char_p, []),
+    "tsc_dict_create": (_c.c_int, [_c.POINTER(_c.c_void_p), _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                   _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "tsc_dict_destroy": (_c.c_int, [_c.c_void_p]),
+    "tsc_encode_dense": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p]),
+    "tsc_topk_recommended_slots": (_c.c_int, [_c.c_int]),
+    "tsc_topk_state_reset": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
+    "tsc_encode_topk": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
+    "tsc_topk_merge": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
+                                  _c.c_void_p, _c.c_void_p]),
+    "tsc_topk_finalize": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "tsc_encode_sparse": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                     _c.c_void_p, _c.c_void_p]),
+    "tsc_decode_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p]),
+    "tsc_decode_sparse": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int,
+                                     _c.c_void_p, _c.c_void_p]),
+    "tsc_contrib_scores": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int,
+                                      _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class TscError(RuntimeError):
+    """Non-zero status from the C-ABI (the reference raises Python exceptions, so do we)."""
+
+
+class _TopkStateStruct(ctypes.Structure):
+    _fields_ = [("vals", _c.c_void_p), ("idx", _c.c_void_p), ("d_sae", _c.c_int32), ("k", _c.c_int32),
+                ("n_slots", _c.c_int32)]
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Load the HIP library or fail loudly -- there is no CPU path behind this package."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise TscError(
+                f"{_LIB_PATH} is missing: build it with `make -C transcoder-sae-circuits_amd/csrc` "
+                "(or __graft_entry__.build()); the MI355X path has no fallback")
+        handle = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise TscError(f"libtsc_hip status {rc}: {lib().tsc_last_error().decode()}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise TscError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TscError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise TscError(f"{name} must be contiguous")
+    return t
+
+
+class DeviceDict:
+    """One transcoder / z-SAE registered with the library (``tsc_dict_create``).  Keeps the
+    weight tensors alive for as long as the handle borrows their memory."""
+
+    def __init__(self, W_enc, b_enc, b_dec, W_dec=None, out_bias=None, compute_dtype: int = F32):
+        self._handle = ctypes.c_void_p()
+        self._keep = [_dev(W_enc, torch.float32, "W_enc"), _dev(b_enc, torch.float32, "b_enc"),
+                      _dev(b_dec, torch.float32, "b_dec")]
+        self.d_in, self.d_sae = W_enc.shape
+        self.d_out = self.d_in
+        ptr_dec = ptr_bias = None
+        if W_dec is not None:
+            self._keep.append(_dev(W_dec, torch.float32, "W_dec"))
+            self.d_out = W_dec.shape[1]
+            ptr_dec = W_dec.data_ptr()
+        if out_bias is not None:
+            self._keep.append(_dev(out_bias, torch.float32, "out_bias"))
+            ptr_bias = out_bias.data_ptr()
+        self.device = W_enc.device
+        self.compute_dtype = compute_dtype
+        with torch.cuda.device(self.device):
+            _check(lib().tsc_dict_create(ctypes.byref(self._handle), self.d_in, self.d_sae, self.d_out,
+                                         compute_dtype, W_enc.data_ptr(), b_enc.data_ptr(), b_dec.data_ptr(),
+                                         ptr_dec, ptr_bias, _stream()))
+
+    def same_storage(self, *tensors) -> bool:
+        return all(a.data_ptr() == b.data_ptr() for a, b in zip(self._keep, tensors))
+
+    def close(self) -> None:
+        if self._handle:
+            lib().tsc_dict_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ dense
+    def encode_dense(self, x: torch.Tensor) -> torch.Tensor:
+        """``relu((x - b_dec) @ W_enc + b_enc)`` for ``x [..., d_in]`` -> ``[..., d_sae]``."""
+        x2 = _dev(x, torch.float32, "x").reshape(-1, self.d_in)
+        out = torch.empty(x2.shape[0], self.d_sae, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _check(lib().tsc_encode_dense(self._handle, x2.data_ptr(), x2.shape[0], out.data_ptr(), _stream()))
+        return out.reshape(*x.shape[:-1], self.d_sae)
+
+    # ------------------------------------------------------------------ top-k
+    def encode_topk(self, x: torch.Tensor, token_id_base: int, state: "TopkState") -> None:
+        x2 = _dev(x, torch.float32, "x").reshape(-1, self.d_in)
+        with torch.cuda.device(x.device):
+            _check(lib().tsc_encode_topk(self._handle, x2.data_ptr(), x2.shape[0], int(token_id_base),
+                                         ctypes.byref(state._struct), _stream()))
+
+    # ------------------------------------------------------------------ sparse
+    def encode_sparse(self, x: torch.Tensor, max_active: int = 512) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Per row the active features, value-descending: ``(feat int32 [M,cap], val [M,cap],
+        count int32 [M])``.  Grows the capacity and retries if a row overflows it."""
+        x2 = _dev(x, torch.float32, "x").reshape(-1, self.d_in)
+        m = x2.shape[0]
+        cap = max(1, min(int(max_active), MAX_ACTIVE_LIMIT, self.d_sae))
+        while True:
+            feat = torch.empty(m, cap, dtype=torch.int32, device=x.device)
+            val = torch.empty(m, cap, dtype=torch.float32, device=x.device)
+            count = torch.empty(m, dtype=torch.int32, device=x.device)
+            with torch.cuda.device(x.device):
+                _check(lib().tsc_encode_sparse(self._handle, x2.data_ptr(), m, cap, feat.data_ptr(), val.data_ptr(),
+                                               count.data_ptr(), _stream()))
+            worst = int(count.max()) if m else 0
+            if worst <= cap:
+                return feat, val, count
+            if cap >= min(MAX_ACTIVE_LIMIT, self.d_sae):
+                raise TscError(f"a row has {worst} active features, above the {MAX_ACTIVE_LIMIT} the sparse path holds")
+            cap = min(MAX_ACTIVE_LIMIT, self.d_sae, max(2 * cap, worst))
+
+    def decode_rows(self, feat: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
+        """``val[i] * W_dec[feat[i]]`` -> ``[n, d_out]``."""
+        feat = _dev(feat, torch.int32, "feat").reshape(-1)
+        val = _dev(val, torch.float32, "val").reshape(-1)
+        rows = torch.empty(feat.numel(), self.d_out, dtype=torch.float32, device=feat.device)
+        with torch.cuda.device(feat.device):
+            _check(lib().tsc_decode_rows(self._handle, feat.data_ptr(), val.data_ptr(), feat.numel(), rows.data_ptr(),
+                                         _stream()))
+        return rows
+
+    def decode_sparse(self, feat, val, count) -> torch.Tensor:
+        """``out_bias + sum_i val[m,i] * W_dec[feat[m,i]]`` -> ``[M, d_out]``."""
+        _dev(feat, torch.int32, "feat"); _dev(val, torch.float32, "val"); _dev(count, torch.int32, "count")
+        m, cap = feat.shape
+        recon = torch.empty(m, self.d_out, dtype=torch.float32, device=feat.device)
+        with torch.cuda.device(feat.device):
+            _check(lib().tsc_decode_sparse(self._handle, feat.data_ptr(), val.data_ptr(), count.data_ptr(), m, cap,
+                                           recon.data_ptr(), _stream()))
+        return recon
+
+    def contrib_scores(self, feat, val, count, dirs: torch.Tensor) -> torch.Tensor:
+        """``val[m,i] * (W_dec[feat[m,i]] . dirs[d])`` -> ``[M, cap, n_dir]``."""
+        _dev(feat, torch.int32, "feat"); _dev(val, torch.float32, "val"); _dev(count, torch.int32, "count")
+        dirs = _dev(dirs, torch.float32, "dirs").reshape(-1, self.d_out)
+        m, cap = feat.shape
+        out = torch.empty(m, cap, dirs.shape[0], dtype=torch.float32, device=feat.device)
+        with torch.cuda.device(feat.device):
+            _check(lib().tsc_contrib_scores(self._handle, feat.data_ptr(), val.data_ptr(), count.data_ptr(), m, cap,
+                                            dirs.data_ptr(), dirs.shape[0], out.data_ptr(), _stream()))
+        return out
+
+
+class TopkState:
+    """Caller-owned running top-k lists: ``vals [n_slots, d_sae, k]`` fp32 and ``idx`` int64."""
+
+    def __init__(self, d_sae: int, k: int = 20, device="cuda", n_slots: Optional[int] = None):
+        if n_slots is None:
+            n_slots = lib().tsc_topk_recommended_slots(d_sae)
+        self.d_sae, self.k, self.n_slots = int(d_sae), int(k), int(n_slots)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise TscError("top-k state must live on the GPU")
+        self.vals = torch.empty(self.n_slots, d_sae, k, dtype=torch.float32, device=self.device)
+        self.idx = torch.empty(self.n_slots, d_sae, k, dtype=torch.int64, device=self.device)
+        self._struct = _TopkStateStruct(self.vals.data_ptr(), self.idx.data_ptr(), d_sae, k, self.n_slots)
+        self.reset()
+
+    def reset(self) -> None:
+        with torch.cuda.device(self.device):
+            _check(lib().tsc_topk_state_reset(ctypes.byref(self._struct), _stream()))
+
+    def finalize(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Merged, sorted ``(vals [d_sae,k], idx [d_sae,k])``; the state stays usable."""
+        ov = torch.empty(self.d_sae, self.k, dtype=torch.float32, device=self.device)
+        oi = torch.empty(self.d_sae, self.k, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(lib().tsc_topk_finalize(ctypes.byref(self._struct), ov.data_ptr(), oi.data_ptr(), _stream()))
+        return ov, oi
+
+    def load(self, vals: torch.Tensor, idx: torch.Tensor) -> None:
+        """Resume from finalized lists: they become slot 0, the other slots are emptied."""
+        self.reset()
+        self.vals[0].copy_(vals)
+        self.idx[0].copy_(idx)
+
+
+def topk_merge(vals: torch.Tensor, idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Merge ``[n_lists, d_sae, k]`` list sets (e.g. the all-gathered per-rank lists)."""
+    vals = _dev(vals, torch.float32, "vals")
+    idx = _dev(idx, torch.int64, "idx")
+    n_lists, d_sae, k = vals.shape
+    ov = torch.empty(d_sae, k, dtype=torch.float32, device=vals.device)
+    oi = torch.empty(d_sae, k, dtype=torch.int64, device=vals.device)
+    with torch.cuda.device(vals.device):
+        _check(lib().tsc_topk_merge(vals.data_ptr(), idx.data_ptr(), n_lists, d_sae, k, ov.data_ptr(), oi.data_ptr(),
+                                    _stream()))
+    return ov, oi
