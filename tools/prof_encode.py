@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Short profiling target: N launches of the fused encode+top-k on one dictionary.
+Used under rocprofv3 (--kernel-trace --stats, or one --pmc pass at a time); not a test."""
+import argparse
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(REPO, "transcoder-sae-circuits_amd"), REPO):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--d-sae", type=int, default=24576)
+ap.add_argument("--tokens", type=int, default=16384)
+ap.add_argument("--launches", type=int, default=12)
+ap.add_argument("--mode", default="topk", choices=["topk", "dense", "sparse"])
+ap.add_argument("--slots", type=int, default=0)
+ap.add_argument("--bf16", action="store_true")
+args = ap.parse_args()
+
+import tsc_hip  # noqa: E402
+from bench import make_device_dictionary  # noqa: E402
+
+dev = torch.device("cuda", 0)
+W, be, bd = make_device_dictionary(args.d_sae, 1, dev)
+d = tsc_hip.DeviceDict(W, be, bd, compute_dtype=tsc_hip.BF16 if args.bf16 else tsc_hip.F32)
+st = tsc_hip.TopkState(args.d_sae, 20, dev, n_slots=args.slots or None)
+g = torch.Generator(device=dev).manual_seed(3)
+xs = [torch.randn(args.tokens, 768, generator=g, device=dev) for _ in range(args.launches)]
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for i, x in enumerate(xs):
+    if i == args.launches // 2:
+        e0.record()
+    if args.mode == "topk":
+        d.encode_topk(x, i * args.tokens, st)
+    elif args.mode == "dense":
+        out = d.encode_dense(x)
+    else:
+        out = d.encode_sparse(x, 512)
+e1.record()
+torch.cuda.synchronize()
+n = args.launches - args.launches // 2
+ms = e0.elapsed_time(e1) / n
+print(f"{args.mode} d_sae={args.d_sae} tokens={args.tokens}: {ms:.3f} ms/launch, "
+      f"{2.0 * 768 * args.d_sae * args.tokens / ms / 1e9:.1f} TFLOP/s")
