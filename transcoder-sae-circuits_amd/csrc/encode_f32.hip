@@ -37,14 +37,13 @@ struct __attribute__((aligned(16))) Smem {
     float thr[BN];
     float q_val[QCAP];
     int q_loc[QCAP];  // (row in tile << 8) | column in tile
+    // per-feature list state, owned by thread t < BN: entries held, and the lowest-ranked entry
+    long long f_worst_id[BN];
+    float f_worst_v[BN];
+    int f_worst_pos[BN];
+    int f_cnt[BN];
     int q_count;
     int pad[3];
-};
-
-struct FeatState {  // the owning thread's view of one feature's list
-    int cnt, worst_pos;
-    float worst_v;
-    long long worst_id;
 };
 
 __device__ __forceinline__ bool ranks_below(float v, long long id, float w, long long wid) {
@@ -88,29 +87,30 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
         be[bn] = nok[bn] ? a.b_enc[n] : 0.f;
     }
 
-    // TOPK: thread t < BN owns feature n0 + t of list set `slot`
-    FeatState st = {0, 0, 0.f, 0};
-    float *lv = nullptr;
-    long long *lid = nullptr;
+    // TOPK: thread t < BN owns feature n0 + t of list set `slot`; its view of the list (kept in
+    // LDS, not registers: the main loop is register-bound) is rebuilt from HBM at start-up
     if (MODE == TSC_MODE_TOPK) {
         if (tid < BN) {
-            float t = 0.f;
+            int cnt = 0, wpos = 0;
+            float wv = 0.f;
+            long long wid = 0;
             if (n0 + tid < a.N) {
                 const long long off = ((long long)slot * a.N + n0 + tid) * a.topk;
-                lv = a.tk_vals + off;
-                lid = a.tk_idx + off;
                 for (int i = 0; i < a.topk; ++i) {
-                    const long long id = lid[i];
+                    const long long id = a.tk_idx[off + i];
                     if (id < 0) break;
-                    const float v = lv[i];
-                    if (i == 0 || ranks_below(v, id, st.worst_v, st.worst_id)) {
-                        st.worst_v = v; st.worst_id = id; st.worst_pos = i;
+                    const float v = a.tk_vals[off + i];
+                    if (i == 0 || ranks_below(v, id, wv, wid)) {
+                        wv = v; wid = id; wpos = i;
                     }
-                    st.cnt = i + 1;
+                    cnt = i + 1;
                 }
-                t = st.cnt == a.topk ? st.worst_v : 0.f;
             }
-            sm.thr[tid] = t;
+            sm.f_cnt[tid] = cnt;
+            sm.f_worst_pos[tid] = wpos;
+            sm.f_worst_v[tid] = wv;
+            sm.f_worst_id[tid] = wid;
+            sm.thr[tid] = cnt == a.topk ? wv : 0.f;
         }
         __syncthreads();
     }
@@ -123,21 +123,26 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
     // "load or zero" makes hipcc branch around every load and drain the queue per element.
     // Rows past M and columns past N then hold finite copies of real data and are masked in the
     // epilogue; k past K is zeroed on the W side while staging (so x garbage there multiplies 0).
+    // Addresses are a wave-uniform 64-bit base plus a 32-bit lane offset (saddr form): 64-bit
+    // per-lane pointers would cost 2 VGPRs per load in a loop that has none to spare.
     const int nc = n0 + b_col < a.N - 4 ? n0 + b_col : a.N - 4;
     auto gload = [&](long long m0, int k0) {
         const int kc = k0 + a_col < a.K - 4 ? k0 + a_col : a.K - 4;
         rbd = *(const f32x4 *)(a.b_dec + kc);
+        const char *xt = (const char *)(a.x + m0 * a.K);
+        const long long rows_left = a.M - m0;  // >= 1
+        const int rmax = rows_left > BM ? BM - 1 : (int)rows_left - 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            long long r = m0 + a_row + 32 * i;
-            r = r < a.M ? r : a.M - 1;
-            ra[i] = *(const f32x4 *)(a.x + r * a.K + kc);
+            const int r = a_row + 32 * i < rmax ? a_row + 32 * i : rmax;
+            ra[i] = *(const f32x4 *)(xt + (unsigned)(r * a.K + kc) * 4u);
         }
+        const char *wt = (const char *)a.W;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int kr = k0 + b_row + 8 * i;
             kr = kr < a.K ? kr : a.K - 1;
-            rb[i] = *(const f32x4 *)(a.W + (long long)kr * a.N + nc);
+            rb[i] = *(const f32x4 *)(wt + ((size_t)kr * a.N + nc) * 4u);
         }
     };
     auto sstore = [&](int buf, int k0) {
@@ -150,7 +155,39 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
             *(f32x4 *)&sm.B[buf][(b_row + 8 * i) * LDB + b_col] = (k0 + b_row + 8 * i < a.K) ? rb[i] : z;
     };
 
-    for (long long mt = slot; mt < n_mtiles; mt += a.m_split) {
+    // Fragments of one group of 8 k (4 MFMA k-steps): MFMA step s contracts k = 8*kk + 4*lh + s
+    // (lane half lh).  Any bijection works as long as A and B agree, and this one makes the A
+    // fragment a single 16-byte LDS read.
+    struct Frag {
+        f32x4 af[2], bf[2];
+    };
+    auto ldfrag = [&](int buf, int kk, Frag &f) {
+        const float *As = sm.A[buf];
+        const float *Bs = sm.B[buf];
+#pragma unroll
+        for (int bm = 0; bm < 2; ++bm)
+            f.af[bm] = *(const f32x4 *)&As[(wm0 + bm * 32 + li) * LDA + kk * 8 + lh * 4];
+#pragma unroll
+        for (int bn = 0; bn < 2; ++bn)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                f.bf[bn][s] = Bs[(kk * 8 + lh * 4 + s) * LDB + wn0 + bn * 32 + li];
+    };
+
+    // The workgroup's work is one continuous stream of k-steps over all its token tiles: the
+    // prefetch of a tile's first k-step is issued during the previous tile's last one, and the
+    // epilogue runs with the next tile's first k-step already staged.
+    int parity = 0;
+    long long mt = slot;
+    if (mt < n_mtiles) {
+        gload(mt * BM, 0);
+        sstore(0, 0);
+    }
+    __syncthreads();
+    Frag F, G;
+    if (mt < n_mtiles) ldfrag(0, 0, F);
+
+    for (; mt < n_mtiles; mt += a.m_split) {
         const long long m0 = mt * BM;
         f32x16 acc[2][2];
 #pragma unroll
@@ -160,47 +197,50 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[bm][bn][r] = 0.f;
 
-        gload(m0, 0);
-        sstore(0, 0);
-        __syncthreads();
+#define TSC_MFMA(FR, S0, S1)                                                                   \
+    _Pragma("unroll") for (int s = S0; s < S1; ++s) _Pragma("unroll") for (int bm = 0; bm < 2; ++bm) \
+        _Pragma("unroll") for (int bn = 0; bn < 2; ++bn) acc[bm][bn] =                         \
+            __builtin_amdgcn_mfma_f32_32x32x2f32(FR.af[bm][s], FR.bf[bn][s], acc[bm][bn], 0, 0, 0);
+
         for (int kt = 0; kt < nk; ++kt) {
-            const bool more = kt + 1 < nk;
-            if (more) gload(m0, (kt + 1) * BK);
-            const float *As = sm.A[kt & 1];
-            const float *Bs = sm.B[kt & 1];
-#pragma unroll
-            for (int kk = 0; kk < BK / 8; ++kk) {
-                // MFMA step s of this group contracts k = 8*kk + 4*lh + s (lane half lh): any
-                // bijection works as long as A and B agree, and this one makes the A fragment one
-                // 16-byte LDS read.
-                f32x4 af[2], bf[2];
-#pragma unroll
-                for (int bm = 0; bm < 2; ++bm)
-                    af[bm] = *(const f32x4 *)&As[(wm0 + bm * 32 + li) * LDA + kk * 8 + lh * 4];
-#pragma unroll
-                for (int bn = 0; bn < 2; ++bn)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        bf[bn][s] = Bs[(kk * 8 + lh * 4 + s) * LDB + wn0 + bn * 32 + li];
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int bm = 0; bm < 2; ++bm)
-#pragma unroll
-                        for (int bn = 0; bn < 2; ++bn)
-                            acc[bm][bn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[bm][s], bf[bn][s],
-                                                                               acc[bm][bn], 0, 0, 0);
-            }
-            if (more) sstore((kt + 1) & 1, (kt + 1) * BK);
+            // what to prefetch: the next k-step of this tile, or the first of the next tile
+            const bool last_k = kt + 1 == nk;
+            const long long next_m0 = last_k ? (mt + a.m_split) * BM : m0;
+            const int next_k0 = last_k ? 0 : (kt + 1) * BK;
+            const bool more = !last_k || mt + a.m_split < n_mtiles;
+#ifndef TSC_EXP_NOLOAD
+            if (more) gload(next_m0, next_k0);
+#endif
+            ldfrag(parity, 1, G);
+            TSC_MFMA(F, 0, 4)
+            ldfrag(parity, 2, F);
+            TSC_MFMA(G, 0, 4)
+            ldfrag(parity, 3, G);
+            TSC_MFMA(F, 0, 4)
+            // stage the prefetched k-step into the other buffer (free since the last barrier),
+            // cover the LDS write latency and the barrier with the first half of the last group,
+            // and the first fragment read of the new buffer with the second half
+            if (more) sstore(parity ^ 1, next_k0);
+            TSC_MFMA(G, 0, 2)
             __syncthreads();
+            if (more) ldfrag(parity ^ 1, 0, F);
+            TSC_MFMA(G, 2, 4)
+            parity ^= 1;
         }
+#undef TSC_MFMA
 
         // ---------------------------------------------------------------- epilogues
-        // C layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+        // C layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+        // The lane's row/column bases are made opaque once per tile: otherwise hipcc hoists the 64
+        // per-element row ids / addresses out of the tile loop and spills them around the k-loop.
+        int rbase = wm0 + 4 * lh, cbase = wn0 + li;
+        asm volatile("" : "+v"(rbase), "+v"(cbase));
+        const long long rows_left = a.M - m0;
+        const int lim = (rows_left > BM ? BM : (int)rows_left) - rbase;  // element row offset c is valid iff c < lim
 #define TSC_FOR_ACC(BODY)                                                                     \
     _Pragma("unroll") for (int bm = 0; bm < 2; ++bm) _Pragma("unroll") for (int bn = 0; bn < 2; ++bn) \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
-        const int ml = wm0 + bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;                       \
+        const int c = bm * 32 + (r & 3) + 8 * (r >> 2);                                       \
         const float v = acc[bm][bn][r];                                                       \
         BODY                                                                                  \
     }
@@ -213,29 +253,38 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
                 for (int r = 0; r < 16; ++r) acc[bm][bn][r] += be[bn];
 
         if (MODE == TSC_MODE_DENSE) {
+            float *obase = a.out + (m0 + rbase) * a.N + (n0 + cbase);
             TSC_FOR_ACC({
-                const long long row = m0 + ml;
-                if (nok[bn] && row < a.M)
-                    __builtin_nontemporal_store(v > 0.f ? v : 0.f,
-                                                a.out + row * a.N + (n0 + wn0 + bn * 32 + li));
+                if (nok[bn] && c < lim)
+                    __builtin_nontemporal_store(v > 0.f ? v : 0.f, obase + (size_t)c * a.N + bn * 32);
             })
         } else if (MODE == TSC_MODE_SPARSE) {
             TSC_FOR_ACC({
-                const long long row = m0 + ml;
-                if (v > 0.f && nok[bn] && row < a.M) {
+                if (v > 0.f && nok[bn] && c < lim) {
+                    const long long row = m0 + rbase + c;
                     const int pos = atomicAdd(a.sp_count + row, 1);
                     if (pos < a.max_active) {
-                        a.sp_feat[row * a.max_active + pos] = n0 + wn0 + bn * 32 + li;
+                        a.sp_feat[row * a.max_active + pos] = n0 + cbase + bn * 32;
                         a.sp_val[row * a.max_active + pos] = v;
                     }
                 }
             })
         } else {
+            // Fast path: the lane's largest value per feature against that feature's k-th best.
+            // Rows past M are copies of the last real row, so they cannot raise a false alarm that
+            // the exact re-check below would not dismiss.
             float thr[2];
-            thr[0] = sm.thr[wn0 + li];
-            thr[1] = sm.thr[wn0 + 32 + li];
             int any = 0;
-            TSC_FOR_ACC({ any |= (v > 0.f && v >= thr[bn] && nok[bn] && m0 + ml < a.M) ? 1 : 0; })
+#pragma unroll
+            for (int bn = 0; bn < 2; ++bn) {
+                thr[bn] = nok[bn] ? sm.thr[cbase + bn * 32] : __builtin_inff();
+                float mx = acc[0][bn][0];
+#pragma unroll
+                for (int bm = 0; bm < 2; ++bm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[bm][bn][r]);
+                any |= (mx > 0.f && mx >= thr[bn]) ? 1 : 0;
+            }
             if (__syncthreads_or(any)) {
                 // Rare path.  Candidates are handed to the owning threads through a bounded LDS
                 // queue; a lane whose push finds the queue full keeps its place and the round is
@@ -246,12 +295,12 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
                     __syncthreads();
                     int ord = 0, blocked = 0;
                     TSC_FOR_ACC({
-                        if (v > 0.f && v >= thr[bn] && nok[bn] && m0 + ml < a.M) {
+                        if (v > 0.f && v >= thr[bn] && c < lim) {
                             if (ord >= consumed && !blocked) {
                                 const int pos = atomicAdd(&sm.q_count, 1);
                                 if (pos < QCAP) {
                                     sm.q_val[pos] = v;
-                                    sm.q_loc[pos] = (ml << 8) | (wn0 + bn * 32 + li);
+                                    sm.q_loc[pos] = ((rbase + c) << 8) | (cbase + bn * 32);
                                     ++consumed;
                                 } else {
                                     blocked = 1;
@@ -261,38 +310,46 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
                         }
                     })
                     __syncthreads();
-                    if (tid < BN) {
+                    if (tid < BN && n0 + tid < a.N) {
                         const int nq = sm.q_count < QCAP ? sm.q_count : QCAP;
-                        if (lv != nullptr) {
-                            for (int e = 0; e < nq; ++e) {
-                                const int loc = sm.q_loc[e];
-                                if ((loc & 255) != tid) continue;
-                                const float v = sm.q_val[e];
-                                const long long id = a.token_base + m0 + (loc >> 8);
-                                if (st.cnt < a.topk) {
-                                    lv[st.cnt] = v;
-                                    lid[st.cnt] = id;
-                                    if (st.cnt == 0 || ranks_below(v, id, st.worst_v, st.worst_id)) {
-                                        st.worst_v = v; st.worst_id = id; st.worst_pos = st.cnt;
-                                    }
-                                    ++st.cnt;
-                                } else if (ranks_below(st.worst_v, st.worst_id, v, id)) {
-                                    const int p = st.worst_pos;
-                                    lv[p] = v;
-                                    lid[p] = id;
-                                    st.worst_v = v; st.worst_id = id;  // rescan; slot p from registers
-                                    for (int i = 0; i < a.topk; ++i) {
-                                        if (i == p) continue;
-                                        const float ev = lv[i];
-                                        const long long eid = lid[i];
-                                        if (ranks_below(ev, eid, st.worst_v, st.worst_id)) {
-                                            st.worst_v = ev; st.worst_id = eid; st.worst_pos = i;
-                                        }
+                        const long long off = ((long long)slot * a.N + n0 + tid) * a.topk;
+                        float *lv = a.tk_vals + off;
+                        long long *lid = a.tk_idx + off;
+                        int cnt = sm.f_cnt[tid], wpos = sm.f_worst_pos[tid];
+                        float wv = sm.f_worst_v[tid];
+                        long long wid = sm.f_worst_id[tid];
+                        for (int e = 0; e < nq; ++e) {
+                            const int loc = sm.q_loc[e];
+                            if ((loc & 255) != tid) continue;
+                            const float v = sm.q_val[e];
+                            const long long id = a.token_base + m0 + (loc >> 8);
+                            if (cnt < a.topk) {
+                                lv[cnt] = v;
+                                lid[cnt] = id;
+                                if (cnt == 0 || ranks_below(v, id, wv, wid)) {
+                                    wv = v; wid = id; wpos = cnt;
+                                }
+                                ++cnt;
+                            } else if (ranks_below(wv, wid, v, id)) {
+                                const int p = wpos;
+                                lv[p] = v;
+                                lid[p] = id;
+                                wv = v; wid = id;  // rescan for the new lowest; slot p from registers
+                                for (int i = 0; i < a.topk; ++i) {
+                                    if (i == p) continue;
+                                    const float ev = lv[i];
+                                    const long long eid = lid[i];
+                                    if (ranks_below(ev, eid, wv, wid)) {
+                                        wv = ev; wid = eid; wpos = i;
                                     }
                                 }
                             }
-                            sm.thr[tid] = st.cnt == a.topk ? st.worst_v : 0.f;
                         }
+                        sm.f_cnt[tid] = cnt;
+                        sm.f_worst_pos[tid] = wpos;
+                        sm.f_worst_v[tid] = wv;
+                        sm.f_worst_id[tid] = wid;
+                        sm.thr[tid] = cnt == a.topk ? wv : 0.f;
                     }
                     if (!__syncthreads_or(blocked)) break;
                 }
