@@ -96,14 +96,23 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
             long long wid = 0;
             if (n0 + tid < a.N) {
                 const long long off = ((long long)slot * a.N + n0 + tid) * a.topk;
-                for (int i = 0; i < a.topk; ++i) {
-                    const long long id = a.tk_idx[off + i];
-                    if (id < 0) break;
-                    const float v = a.tk_vals[off + i];
-                    if (i == 0 || ranks_below(v, id, wv, wid)) {
-                        wv = v; wid = id; wpos = i;
+                for (int i0 = 0; i0 < a.topk; i0 += 8) {  // lists are compact: live entries first
+                    float ev[8];
+                    long long eid[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = i0 + j < a.topk ? i0 + j : a.topk - 1;
+                        ev[j] = a.tk_vals[off + i];
+                        eid[j] = a.tk_idx[off + i];
                     }
-                    cnt = i + 1;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (i0 + j < a.topk && eid[j] >= 0) {
+                            if (cnt == 0 || ranks_below(ev[j], eid[j], wv, wid)) {
+                                wv = ev[j]; wid = eid[j]; wpos = i0 + j;
+                            }
+                            cnt = i0 + j + 1;
+                        }
                 }
             }
             sm.f_cnt[tid] = cnt;
@@ -112,6 +121,7 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
             sm.f_worst_id[tid] = wid;
             sm.thr[tid] = cnt == a.topk ? wv : 0.f;
         }
+        if (tid == 0) sm.q_count = 0;
         __syncthreads();
     }
 
@@ -270,9 +280,13 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
                 }
             })
         } else {
-            // Fast path: the lane's largest value per feature against that feature's k-th best.
-            // Rows past M are copies of the last real row, so they cannot raise a false alarm that
-            // the exact re-check below would not dismiss.
+            // Lane-local pre-check: the lane's largest value per feature against that feature's
+            // k-th best (rows past M are copies of the last real row, so they cannot raise an alarm
+            // that the exact check below would not dismiss).  Lanes with a candidate push it on a
+            // bounded LDS queue; the thread that owns the feature folds it into the feature's list
+            // in HBM.  A lane whose push finds the queue full keeps its place and the round is
+            // repeated, so nothing is dropped whatever the data.  Cost: one barrier per tile when
+            // nobody has a candidate, two when somebody has.
             float thr[2];
             int any = 0;
 #pragma unroll
@@ -285,14 +299,9 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
                     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[bm][bn][r]);
                 any |= (mx > 0.f && mx >= thr[bn]) ? 1 : 0;
             }
-            if (__syncthreads_or(any)) {
-                // Rare path.  Candidates are handed to the owning threads through a bounded LDS
-                // queue; a lane whose push finds the queue full keeps its place and the round is
-                // repeated, so nothing is ever dropped whatever the data.
-                int consumed = 0;
-                for (;;) {
-                    if (tid == 0) sm.q_count = 0;
-                    __syncthreads();
+            int consumed = 0;
+            for (;;) {  // sm.q_count == 0 on entry
+                if (any) {
                     int ord = 0, blocked = 0;
                     TSC_FOR_ACC({
                         if (v > 0.f && v >= thr[bn] && c < lim) {
@@ -309,50 +318,65 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
                             ++ord;
                         }
                     })
-                    __syncthreads();
-                    if (tid < BN && n0 + tid < a.N) {
-                        const int nq = sm.q_count < QCAP ? sm.q_count : QCAP;
-                        const long long off = ((long long)slot * a.N + n0 + tid) * a.topk;
-                        float *lv = a.tk_vals + off;
-                        long long *lid = a.tk_idx + off;
-                        int cnt = sm.f_cnt[tid], wpos = sm.f_worst_pos[tid];
-                        float wv = sm.f_worst_v[tid];
-                        long long wid = sm.f_worst_id[tid];
-                        for (int e = 0; e < nq; ++e) {
-                            const int loc = sm.q_loc[e];
-                            if ((loc & 255) != tid) continue;
-                            const float v = sm.q_val[e];
-                            const long long id = a.token_base + m0 + (loc >> 8);
-                            if (cnt < a.topk) {
-                                lv[cnt] = v;
-                                lid[cnt] = id;
-                                if (cnt == 0 || ranks_below(v, id, wv, wid)) {
-                                    wv = v; wid = id; wpos = cnt;
+                }
+                __syncthreads();
+                const int pushed = sm.q_count;  // > QCAP: some lane is blocked and needs another round
+                if (pushed == 0) break;
+                if (tid < BN && n0 + tid < a.N) {
+                    const int nq = pushed < QCAP ? pushed : QCAP;
+                    const int k = a.topk;
+                    const long long off = ((long long)slot * a.N + n0 + tid) * k;
+                    float *lv = a.tk_vals + off;
+                    long long *lid = a.tk_idx + off;
+                    int cnt = sm.f_cnt[tid], wpos = sm.f_worst_pos[tid];
+                    float wv = sm.f_worst_v[tid];
+                    long long wid = sm.f_worst_id[tid];
+                    for (int e = 0; e < nq; ++e) {
+                        const int loc = sm.q_loc[e];
+                        if ((loc & 255) != tid) continue;
+                        const float v = sm.q_val[e];
+                        const long long id = a.token_base + m0 + (loc >> 8);
+                        if (cnt < k) {
+                            lv[cnt] = v;
+                            lid[cnt] = id;
+                            if (cnt == 0 || ranks_below(v, id, wv, wid)) {
+                                wv = v; wid = id; wpos = cnt;
+                            }
+                            ++cnt;
+                        } else if (ranks_below(wv, wid, v, id)) {
+                            const int p = wpos;
+                            lv[p] = v;
+                            lid[p] = id;
+                            wv = v; wid = id;
+                            // find the new lowest-ranked entry; position p is taken from registers,
+                            // the others are read eight at a time so the loads overlap
+                            for (int i0 = 0; i0 < k; i0 += 8) {
+                                float ev[8];
+                                long long eid[8];
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) {
+                                    const int i = i0 + j < k ? i0 + j : k - 1;
+                                    ev[j] = lv[i];
+                                    eid[j] = lid[i];
                                 }
-                                ++cnt;
-                            } else if (ranks_below(wv, wid, v, id)) {
-                                const int p = wpos;
-                                lv[p] = v;
-                                lid[p] = id;
-                                wv = v; wid = id;  // rescan for the new lowest; slot p from registers
-                                for (int i = 0; i < a.topk; ++i) {
-                                    if (i == p) continue;
-                                    const float ev = lv[i];
-                                    const long long eid = lid[i];
-                                    if (ranks_below(ev, eid, wv, wid)) {
-                                        wv = ev; wid = eid; wpos = i;
+#pragma unroll
+                                for (int j = 0; j < 8; ++j)
+                                    if (i0 + j < k && i0 + j != p && ranks_below(ev[j], eid[j], wv, wid)) {
+                                        wv = ev[j]; wid = eid[j]; wpos = i0 + j;
                                     }
-                                }
                             }
                         }
-                        sm.f_cnt[tid] = cnt;
-                        sm.f_worst_pos[tid] = wpos;
-                        sm.f_worst_v[tid] = wv;
-                        sm.f_worst_id[tid] = wid;
-                        sm.thr[tid] = cnt == a.topk ? wv : 0.f;
                     }
-                    if (!__syncthreads_or(blocked)) break;
+                    sm.f_cnt[tid] = cnt;
+                    sm.f_worst_pos[tid] = wpos;
+                    sm.f_worst_v[tid] = wv;
+                    sm.f_worst_id[tid] = wid;
+                    sm.thr[tid] = cnt == k ? wv : 0.f;
                 }
+                __syncthreads();  // lists and thresholds updated; everyone has read q_count
+                if (tid == 0) sm.q_count = 0;
+                if (pushed <= QCAP) break;  // reset is ordered before the next tile's pushes by the k-loop barriers
+                __syncthreads();
             }
         }
 #undef TSC_FOR_ACC
