@@ -142,6 +142,18 @@ int tsc_contrib_scores(const tsc_dict_t *dict, const int32_t *feat, const float 
                        const int32_t *count, int64_t M, int max_active, const float *dirs,
                        int n_dir, float *scores, tsc_stream_t stream);
 
+/*
+ * Scores of a few selected features for every token, without touching the other d_sae - F columns:
+ *   out[m, j] = act( dot(x[m,:] - b_dec, Pt[j,:]) + bias[j] ),  act = ReLU if apply_relu else identity,
+ * Pt [F, d_in] holds the selected encoder columns as rows (W_enc[:, feats] transposed), bias [F],
+ * b_dec [d_in] or NULL, F <= 64, d_in % 4 == 0 and d_in <= 4096.  HBM-bound on x (one pass).
+ * Replaces `encode(acts)[:, feature]` of MaxActAnalysis.active_examples (max_act_analysis.py:231-232)
+ * and both modes of get_feature_scores (autointerpretability.py:226-241), which compute the full
+ * [tokens, d_sae] product to keep F columns.
+ */
+int tsc_project_features(const float *x, int64_t M, int d_in, const float *b_dec, const float *Pt,
+                         const float *bias, int F, int apply_relu, float *out, tsc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,8 +24,8 @@ def _dd(w, **kw):
 
 
 def _close(a, b, rtol=RTOL, atol=ATOL):
-    a = torch.as_tensor(np.asarray(a.cpu() if torch.is_tensor(a) else a), dtype=torch.float64)
-    b = torch.as_tensor(np.asarray(b.cpu() if torch.is_tensor(b) else b), dtype=torch.float64)
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a), dtype=torch.float64)
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if torch.is_tensor(b) else b), dtype=torch.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
     assert torch.allclose(a, b, rtol=rtol, atol=atol), float((a - b).abs().max())
 

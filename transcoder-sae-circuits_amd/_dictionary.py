@@ -1,0 +1,79 @@
+"""Shared machinery of the two dictionary classes: the link between an ``nn.Module``'s parameters and
+its registration with ``libtsc_hip`` (``tsc_hip.DeviceDict``).  The handle borrows the parameters'
+device memory, so it is rebuilt whenever a parameter is re-allocated (``.to()``, ``load_state_dict``
+into new storage)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+import tsc_hip
+
+try:  # the reference uses TransformerLens hook points; identical-behaving stand-ins when it is absent
+    from transformer_lens.hook_points import HookPoint  # type: ignore
+except Exception:  # pragma: no cover - transformer_lens is not installed offline
+
+    class HookPoint(nn.Module):
+        """Identity unless a forward hook is attached (what a TransformerLens HookPoint is)."""
+
+        def forward(self, x):
+            return x
+
+
+class HipDictionaryMixin:
+    """Expects ``W_enc, b_enc, b_dec, W_dec`` parameters and ``_out_bias()`` on the host class."""
+
+    _hip: Optional[tsc_hip.DeviceDict] = None
+    _hip_bf16: Optional[tsc_hip.DeviceDict] = None
+
+    def _out_bias(self) -> torch.Tensor:  # pragma: no cover - overridden
+        raise NotImplementedError
+
+    def _require_gpu_fp32(self) -> None:
+        p = self.W_enc
+        if not p.is_cuda:
+            raise tsc_hip.TscError(
+                f"{type(self).__name__} lives on {p.device}: the MI355X path runs on a GPU only and has no CPU "
+                "fallback (the reference's CPU branch is the oracle's job, not the product's)")
+        if p.dtype != torch.float32:
+            raise tsc_hip.TscError(f"{type(self).__name__} weights must be float32 (got {p.dtype})")
+
+    def device_dict(self, bf16: bool = False) -> tsc_hip.DeviceDict:
+        """The library handle for the current parameter storage (fp32, or the bf16-MFMA variant)."""
+        self._require_gpu_fp32()
+        tensors = (self.W_enc.data, self.b_enc.data, self.b_dec.data, self.W_dec.data, self._out_bias().data)
+        tensors = tuple(t if t.is_contiguous() else t.contiguous() for t in tensors)
+        attr = "_hip_bf16" if bf16 else "_hip"
+        cur = getattr(self, attr)
+        if cur is None or not cur.same_storage(*tensors):
+            if cur is not None:
+                cur.close()
+            cur = tsc_hip.DeviceDict(*tensors, compute_dtype=tsc_hip.BF16 if bf16 else tsc_hip.F32)
+            object.__setattr__(self, attr, cur)
+        return cur
+
+    # ---- capabilities beyond the reference API (the fused hot path) ----
+    def new_topk_state(self, k: int = 20, n_slots: Optional[int] = None) -> tsc_hip.TopkState:
+        return tsc_hip.TopkState(self.W_enc.shape[1], k, self.W_enc.device, n_slots=n_slots)
+
+    def encode_topk(self, x: torch.Tensor, token_id_base: int, state: tsc_hip.TopkState, bf16: bool = False) -> None:
+        """Fused encode + per-feature running top-k; the activation matrix is never materialised."""
+        x = x.to(device=self.W_enc.device, dtype=torch.float32).contiguous()
+        self.device_dict(bf16).encode_topk(x, token_id_base, state)
+
+    def encode_sparse(self, x: torch.Tensor, max_active: int = 512):
+        """Per row the active features, value-descending: ``(feat, val, count)``."""
+        x = x.to(device=self.W_enc.device, dtype=torch.float32).contiguous()
+        return self.device_dict().encode_sparse(x, max_active)
+
+    def encode_features(self, x: torch.Tensor, features, relu: bool = True) -> torch.Tensor:
+        """Activations of a few selected features only -> ``[..., len(features)]``."""
+        self._require_gpu_fp32()
+        x = x.to(device=self.W_enc.device, dtype=torch.float32).contiguous()
+        feats = torch.as_tensor(features, device=self.W_enc.device, dtype=torch.long).reshape(-1)
+        Pt = self.W_enc.data.index_select(1, feats).t().contiguous()
+        bias = self.b_enc.data.index_select(0, feats).contiguous()
+        out = tsc_hip.project_features(x, Pt, bias, self.b_dec.data.contiguous(), relu=relu)
+        return out.reshape(*x.shape[:-1], feats.numel())

@@ -1,0 +1,551 @@
+"""CircuitLens: residual-stream decomposition into dictionary features and "lens" contribution
+scores, with the reference's Python surface and batched HIP kernels underneath.
+
+Drop-in for the hot-path part of reference ``src/circuit_lens.py``:
+``ActiveFeatures`` (:45-323, row layout and index algebra are API), ``ComponentLens`` (:329-523) and
+``CircuitLens`` (:526-1317).  What changed underneath:
+
+* the reference runs 24 weight-bound M=1 dictionary forwards per *position* (:581-659); here each
+  dictionary is run ONCE over all positions of the prompt (``tsc_encode_sparse`` emits the active
+  (feature, value) lists value-descending, ``tsc_decode_sparse`` the reconstructions), and
+  ``get_active_features(pos)`` only gathers ``W_dec`` rows (``tsc_decode_rows``) for that position;
+* contribution scores of the form ``feature_act x W_dec row . direction`` go through
+  ``tsc_contrib_scores`` on the sparse active set (``contribution_scores``, ``get_transcoder_ixg``).
+
+Plotly heat maps are out of scope: ``visualize=True`` prints the ranked labels only.
+"""
+from __future__ import annotations
+
+import bisect
+from dataclasses import dataclass
+from pprint import pprint
+from typing import Any, Dict, List, Optional, Tuple, TypedDict, Union
+
+import torch
+
+from load_model_and_encoders import get_model_encoders
+
+
+class CircuitComponent:
+    Z_FEATURE = "z_feature"
+    MLP_FEATURE = "mlp_feature"
+    ATTN_HEAD = "attn_head"
+    UNEMBED = "unembed"
+    UNEMBED_AT_TOKEN = "unembed_at_token"
+    EMBED = "embed"
+    POS_EMBED = "pos_embed"
+    BIAS_O = "b_O"
+    Z_SAE_ERROR = "z_sae_error"
+    Z_SAE_BIAS = "z_sae_bias"
+    TRANSCODER_ERROR = "transcoder_error"
+    TRANSCODER_BIAS = "transcoder_bias"
+
+
+class LayerKey(TypedDict):
+    mlp: int
+    attn: int
+
+
+BIAS_OFFSET = 0
+Z_ERROR_OFFSET = 1
+Z_BIAS_OFFSET = 2
+NUM_ATTN_AUXILARY_FEATURES = 3
+NUM_MLP_AUXILARY_FEATURES = 2
+NUM_AUXILARY_FEATURES = NUM_ATTN_AUXILARY_FEATURES + NUM_MLP_AUXILARY_FEATURES
+_ATTN_AUX = (CircuitComponent.BIAS_O, CircuitComponent.Z_SAE_ERROR, CircuitComponent.Z_SAE_BIAS)
+_MLP_AUX = (CircuitComponent.TRANSCODER_ERROR, CircuitComponent.TRANSCODER_BIAS)
+
+
+@dataclass
+class ActiveFeatures:
+    """Rows: ``[embed, pos_embed]`` then per layer ``[b_O, z error, z bias, attn features (desc),
+    transcoder error, transcoder bias, mlp features (desc)]``."""
+
+    vectors: torch.Tensor   # [comp, d_model]
+    values: torch.Tensor    # [comp]
+    features: torch.Tensor  # [comp] int, -1 on auxiliary rows
+    keys: List[LayerKey]
+
+    # ---- offsets: attn block of layer l starts at _starts()[l], its mlp block at _mlp_starts()[l]
+    def _starts(self) -> List[int]:
+        out, pos = [], 2
+        for key in self.keys:
+            out.append(pos)
+            pos += key["attn"] + key["mlp"] + NUM_AUXILARY_FEATURES
+        out.append(pos)
+        return out
+
+    def get_total_active_features(self):
+        return sum(key["mlp"] + key["attn"] for key in self.keys)
+
+    def get_total_auxilary_features(self):
+        return 2 + NUM_AUXILARY_FEATURES * len(self.keys)
+
+    def get_attn_start_index(self, layer: int):
+        return self._starts()[min(layer, len(self.keys))]
+
+    def get_mlp_start_index(self, layer: int):
+        return self._starts()[layer] + self.keys[layer]["attn"] + NUM_ATTN_AUXILARY_FEATURES
+
+    def get_vectors_before_comp(self, kind: str, layer: int):
+        end = self._starts()[layer]  # layer == n_layers is allowed: everything
+        if kind == "mlp":
+            end += self.keys[layer]["attn"] + NUM_ATTN_AUXILARY_FEATURES
+        return self.vectors[:end]
+
+    def get_z_error(self, layer: int):
+        return self.vectors[self.get_attn_start_index(layer) + Z_ERROR_OFFSET]
+
+    @property
+    def max_active_features(self):
+        return max(max(key["mlp"], key["attn"]) for key in self.keys)
+
+    def get_reconstructed_resid_pre(self, layer: int):
+        return self.get_vectors_before_comp("attn", layer).sum(dim=0)
+
+    def get_reconstructed_resid_post(self, layer: int):
+        return self.get_vectors_before_comp("attn", layer + 1).sum(dim=0)
+
+    def get_reconstructed_resid_mid(self, layer: int):
+        return self.get_vectors_before_comp("mlp", layer).sum(dim=0)
+
+    def get_reconstructed_attn_out(self, layer: int):
+        a = self.get_attn_start_index(layer)
+        return self.vectors[a: a + self.keys[layer]["attn"] + NUM_ATTN_AUXILARY_FEATURES].sum(dim=0)
+
+    def get_sae_out_reconstruction(self, layer: int):
+        a = self.get_attn_start_index(layer) + Z_BIAS_OFFSET  # z bias + attention features
+        return self.vectors[a: a + self.keys[layer]["attn"] + 1].sum(dim=0)
+
+    def get_transcoder_reconstruction(self, layer: int):
+        m = self.get_mlp_start_index(layer) + 1  # transcoder bias + mlp features
+        return self.vectors[m: m + self.keys[layer]["mlp"] + 1].sum(dim=0)
+
+    def get_attn_feature_vectors(self, layer: int):
+        a = self.get_attn_start_index(layer) + NUM_ATTN_AUXILARY_FEATURES
+        return self.vectors[a: a + self.keys[layer]["attn"]]
+
+    def get_mlp_feature_vectors(self, layer: int):
+        m = self.get_mlp_start_index(layer) + NUM_MLP_AUXILARY_FEATURES
+        return self.vectors[m: m + self.keys[layer]["mlp"]]
+
+    def get_reconstructed_mlp_out(self, layer: int):
+        m = self.get_mlp_start_index(layer)
+        return self.vectors[m: m + self.keys[layer]["mlp"] + NUM_MLP_AUXILARY_FEATURES].sum(dim=0)
+
+    def classify_row(self, i: int) -> Tuple[str, int]:
+        """Row index -> ``(component kind, layer)``."""
+        if i == 0:
+            return CircuitComponent.EMBED, 0
+        if i == 1:
+            return CircuitComponent.POS_EMBED, 0
+        starts = self._starts()
+        layer = bisect.bisect_right(starts, i) - 1
+        off = i - starts[layer]
+        n_attn = self.keys[layer]["attn"]
+        if off < NUM_ATTN_AUXILARY_FEATURES:
+            return _ATTN_AUX[off], layer
+        off -= NUM_ATTN_AUXILARY_FEATURES
+        if off < n_attn:
+            return CircuitComponent.Z_FEATURE, layer
+        off -= n_attn
+        if off < NUM_MLP_AUXILARY_FEATURES:
+            return _MLP_AUX[off], layer
+        return CircuitComponent.MLP_FEATURE, layer
+
+    def get_top_k_features(self, activations: torch.Tensor, k=10):
+        """``[(component, layer, feature, value)]`` for the k largest activations.  As in the
+        reference (:161-238) the list ENDS at the first embed / pos_embed row it meets (the loop
+        there ``break``s out entirely on rows 0 and 1); callers see that truncation, so it is kept."""
+        k = min(k, activations.size(0))
+        values, indices = activations.topk(k=k)
+        feats = self.features[indices].tolist()
+        out = []
+        for v, i, f in zip(values.tolist(), indices.tolist(), feats):
+            kind, layer = self.classify_row(i)
+            out.append((kind, layer, f, v))
+            if i < 2:
+                break
+        return out
+
+    def get_top_k_lens_runs(self, activations, circuit_lens: "CircuitLens", seq_index: int, k=10) -> List["ComponentLensWithValue"]:
+        runs = []
+        for component, layer, feature_i, value in self.get_top_k_features(activations, k=k):
+            runs.append((ComponentLens(circuit_lens=circuit_lens, component=component,
+                                       run_data={"layer": layer, "seq_index": int(seq_index), "feature": feature_i}), value))
+        return runs
+
+    def get_top_k_labels(self, activations, k=10):
+        return [f"{kind} | Layer: {layer} | Feature: {feature_i} | Contribution: {value*100:.3g}%"
+                for kind, layer, feature_i, value in self.get_top_k_features(activations, k=k)]
+
+
+ComponentLensWithValue = Tuple["ComponentLens", float]
+
+
+@dataclass
+class ComponentLens:
+    circuit_lens: "CircuitLens"
+    component: str
+    run_data: Dict[str, Any]
+
+    @property
+    def tuple_id(self):
+        d = self.run_data
+        if self.component == CircuitComponent.UNEMBED:
+            return (self.component, int(d["seq_index"]), int(d["token_id"]))
+        if self.component == CircuitComponent.UNEMBED_AT_TOKEN:
+            return (self.component, d["seq_index"])
+        if self.component == CircuitComponent.ATTN_HEAD:
+            return (self.component, int(d["layer"]), int(d["head"]), int(d["source_index"]),
+                    int(d["destination_index"]), int(d["feature"]))
+        return (self.component, int(d["layer"]), int(d["seq_index"]), int(d["feature"]))
+
+    @classmethod
+    def init_from_tuple_id(cls, tuple_id, circuit_lens):
+        component = tuple_id[0]
+        if component == CircuitComponent.UNEMBED:
+            data = {"seq_index": tuple_id[1], "token_id": tuple_id[2]}
+        elif component == CircuitComponent.UNEMBED_AT_TOKEN:
+            data = {"seq_index": tuple_id[1]}
+        elif component == CircuitComponent.ATTN_HEAD:
+            data = {"layer": tuple_id[1], "head": tuple_id[2], "source_index": tuple_id[3],
+                    "destination_index": tuple_id[4], "feature": tuple_id[5]}
+        else:
+            data = {"layer": tuple_id[1], "seq_index": tuple_id[2], "feature": tuple_id[3]}
+        return cls(circuit_lens=circuit_lens, component=component, run_data=data)
+
+    @classmethod
+    def create_unembed_at_token_lens(cls, circuit_lens: "CircuitLens", seq_index):
+        return cls(circuit_lens=circuit_lens, component=CircuitComponent.UNEMBED_AT_TOKEN, run_data={"seq_index": seq_index})
+
+    @classmethod
+    def create_unembed_lens(cls, circuit_lens: "CircuitLens", seq_index, token):
+        if isinstance(token, str):
+            token = circuit_lens.model.to_single_token(token)
+        return cls(circuit_lens=circuit_lens, component=CircuitComponent.UNEMBED, run_data={"seq_index": seq_index, "token_id": token})
+
+    def __str__(self):
+        return f"{self.component} | " + " | ".join(f"{k}: {v}" for k, v in self.run_data.items())
+
+    __repr__ = __str__
+
+    @property
+    def feature(self):
+        return self.run_data.get("feature", -1)
+
+    def __call__(self, head_type=None, **kwargs) -> Tuple[List[ComponentLensWithValue], Optional[ActiveFeatures]]:
+        cl, d = self.circuit_lens, self.run_data
+        if self.component == CircuitComponent.UNEMBED:
+            return cl.get_unembed_lens(d["token_id"], d["seq_index"], **kwargs)
+        if self.component == CircuitComponent.UNEMBED_AT_TOKEN:
+            seq_index = cl.process_seq_index(d["seq_index"])
+            token_i = cl.tokens[0, seq_index + 1].item()
+            return cl.get_unembed_lens(int(token_i), d["seq_index"], **kwargs)
+        if self.component == CircuitComponent.Z_FEATURE:
+            return cl.get_head_seq_lens_for_z_feature(d["layer"], d["seq_index"], d["feature"], **kwargs), None
+        if self.component == CircuitComponent.Z_SAE_ERROR:
+            return cl.get_head_seq_lens_for_z_error(d["layer"], d["seq_index"], **kwargs), None
+        if self.component == CircuitComponent.ATTN_HEAD:
+            head_type = head_type or "q"
+            if head_type == "q":
+                return cl.get_q_lens_on_head_seq(d["layer"], d["head"], d["source_index"], d["destination_index"], **kwargs)
+            if head_type == "k":
+                return cl.get_k_lens_on_head_seq(d["layer"], d["head"], d["source_index"], d["destination_index"], **kwargs)
+            if head_type == "v":
+                return cl.get_v_lens_at_seq(d["layer"], d["head"], d["source_index"], d["feature"], **kwargs)
+        if self.component == CircuitComponent.MLP_FEATURE:
+            return cl.get_mlp_feature_lens_at_seq(d["layer"], d["seq_index"], d["feature"], **kwargs)
+        return [], None
+
+
+class CircuitLens:
+    def __init__(self, prompt):
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        model, z_saes, mlp_transcoders = get_model_encoders(self.device)
+        self.z_saes = z_saes
+        self.mlp_transcoders = mlp_transcoders
+        self.model = model
+        self.prompt = prompt
+        self.tokens = self.model.to_tokens(prompt)
+        if self.tokens.size(0) != 1:
+            raise ValueError("Can only do CircuitLens on a single prompt!")
+        with torch.no_grad():
+            self.logits, self.cache = self.model.run_with_cache(self.tokens, return_type="logits")
+        self._seq_activations: Dict[int, ActiveFeatures] = {}
+        self._layer_sparse: Dict[Tuple[str, int], Tuple[torch.Tensor, ...]] = {}
+
+    @property
+    def n_tokens(self):
+        return self.tokens.size(1)
+
+    def normalize_activations(self, activations):
+        return activations / activations.sum()
+
+    def process_seq_index(self, seq_index):
+        if seq_index < 0:
+            seq_index += self.n_tokens
+        return seq_index
+
+    # ------------------------------------------------------------------ batched dictionary passes
+    def _dictionary_input(self, kind: str, layer: int) -> torch.Tensor:
+        if kind == "attn":
+            z = self.cache["z", layer][0]
+            return z.reshape(z.shape[0], -1).contiguous()           # "n_heads d_head -> (n_heads d_head)" per position
+        return self.cache["normalized", layer, "ln2"][0].contiguous()
+
+    def _sparse(self, kind: str, layer: int):
+        """``(feat [n,cap], val [n,cap], count [n], recon [n,d], counts on host)`` for ALL positions."""
+        key = (kind, layer)
+        hit = self._layer_sparse.get(key)
+        if hit is None:
+            enc = self.z_saes[layer] if kind == "attn" else self.mlp_transcoders[layer]
+            with torch.no_grad():
+                feat, val, count = enc.encode_sparse(self._dictionary_input(kind, layer))
+                recon = enc.device_dict().decode_sparse(feat, val, count)
+            hit = (feat, val, count, recon, count.tolist())
+            self._layer_sparse[key] = hit
+        return hit
+
+    def _active(self, kind: str, layer: int, seq_index: int):
+        feat, val, _, recon, counts = self._sparse(kind, layer)
+        c = counts[seq_index]
+        return feat[seq_index, :c], val[seq_index, :c], recon[seq_index]
+
+    def _w_o_flat(self, layer: int) -> torch.Tensor:
+        w = self.model.W_O[layer]
+        return w.reshape(w.shape[0] * w.shape[1], w.shape[2])
+
+    def get_active_features(self, seq_index: int, cache=True) -> ActiveFeatures:
+        seq_index = self.process_seq_index(seq_index)
+        hit = self._seq_activations.get(seq_index)
+        if cache and hit is not None:
+            return hit
+        dev = self.cache["z", 0].device
+        ones = lambda n: torch.ones(n, device=dev)                                    # noqa: E731
+        minus = lambda n: torch.full((n,), -1, dtype=torch.int64, device=dev)         # noqa: E731
+        vectors = [self.cache["embed"][0, seq_index][None], self.cache["pos_embed"][0, seq_index][None]]
+        values, features, keys = [ones(2)], [minus(2)], []
+        with torch.no_grad():
+            for layer in range(self.model.cfg.n_layers):
+                z_sae, tc = self.z_saes[layer], self.mlp_transcoders[layer]
+                w_o = self._w_o_flat(layer)
+                zf, zv, z_recon = self._active("attn", layer, seq_index)
+                layer_z = self._dictionary_input("attn", layer)[seq_index]
+                aux = torch.stack([layer_z - z_recon, z_sae.b_dec]) @ w_o
+                z_rows = z_sae.device_dict().decode_rows(zf, zv) @ w_o if zf.numel() else aux.new_zeros(0, aux.shape[1])
+                vectors += [self.model.b_O[layer][None], aux, z_rows]
+                values += [ones(NUM_ATTN_AUXILARY_FEATURES), zv]
+                features += [minus(NUM_ATTN_AUXILARY_FEATURES), zf.to(torch.int64)]
+
+                mf, mv, m_recon = self._active("mlp", layer, seq_index)
+                mlp_error = self.cache["mlp_out", layer][0, seq_index] - m_recon
+                m_rows = tc.device_dict().decode_rows(mf, mv) if mf.numel() else aux.new_zeros(0, aux.shape[1])
+                vectors += [mlp_error[None], tc.b_dec_out[None], m_rows]
+                values += [ones(NUM_MLP_AUXILARY_FEATURES), mv]
+                features += [minus(NUM_MLP_AUXILARY_FEATURES), mf.to(torch.int64)]
+                keys.append({"mlp": int(mf.numel()), "attn": int(zf.numel())})
+        af = ActiveFeatures(vectors=torch.cat(vectors, dim=0), values=torch.cat(values, dim=0),
+                            features=torch.cat(features, dim=0), keys=keys)
+        self._seq_activations[seq_index] = af
+        return af
+
+    # ------------------------------------------------------------------ contribution scores (sparse form)
+    def contribution_scores(self, kind: str, layer: int, directions: torch.Tensor, seq_index: Optional[int] = None):
+        """``feature_act x W_dec row . direction`` for the active features of ``layer``'s dictionary
+        at every position (or one): returns ``(feat, scores [n, cap, n_dir], count)``.  For attention
+        dictionaries the W_O projection is folded into the directions."""
+        enc = self.z_saes[layer] if kind == "attn" else self.mlp_transcoders[layer]
+        feat, val, count, _, _ = self._sparse(kind, layer)
+        dirs = directions.reshape(-1, directions.shape[-1]).to(torch.float32)
+        if kind == "attn":
+            dirs = dirs @ self._w_o_flat(layer).t()
+        if seq_index is not None:
+            s = self.process_seq_index(seq_index)
+            feat, val, count = feat[s:s + 1].contiguous(), val[s:s + 1].contiguous(), count[s:s + 1].contiguous()
+        return feat, enc.device_dict().contrib_scores(feat, val, count, dirs.contiguous()), count
+
+    # ------------------------------------------------------------------ lens plumbing
+    def get_next_lens_runs(self, active_features: ActiveFeatures, activations, seq_index: int, title: str,
+                           visualize=True, k=None):
+        if k is None:
+            k = 10
+        if visualize:
+            print(title)
+            pprint(active_features.get_top_k_labels(activations, k=k))
+        return active_features.get_top_k_lens_runs(activations, self, seq_index, k=k), active_features
+
+    def get_unembed_lens_for_prompt_token(self, seq_index: int, visualize=True, k=None):
+        seq_index = self.process_seq_index(seq_index)
+        token_i = self.tokens[0, seq_index + 1].item()
+        return self.get_unembed_lens(token_i, seq_index, visualize, k)
+
+    def get_str_token_at_seq(self, seq_index: int):
+        return self.model.tokenizer.decode([self.tokens[0, self.process_seq_index(seq_index)]])
+
+    def get_unembed_lens(self, token_i: Union[int, str], seq_index: int, visualize=True, k=None):
+        if isinstance(token_i, str):
+            token_i = self.model.to_tokens(token_i, prepend_bos=False)[0]
+        seq_index = self.process_seq_index(seq_index)
+        af = self.get_active_features(seq_index)
+        activations = self.normalize_activations(af.vectors @ self.model.W_U[:, token_i])
+        return self.get_next_lens_runs(af, activations, seq_index,
+                                       title=f"Unembed Lens for token '{self.model.tokenizer.decode([token_i])}'/{token_i}",
+                                       visualize=visualize, k=k)
+
+    def get_head_seq_activations_for_vector(self, layer: int, seq_index: int, vector: torch.Tensor):
+        """Contribution of every (head, source position) to ``vector`` read from z at ``seq_index``:
+        ``pattern[h, seq, src] * (v[src, h] . vector[h])`` flattened head-major."""
+        seq_index = self.process_seq_index(seq_index)
+        v = self.cache["v", layer][0]
+        pattern = self.cache["pattern", layer][0, :, seq_index]
+        return (torch.einsum("shd,hd->hs", v, vector) * pattern).reshape(-1)
+
+    def get_head_seq_activations_for_z_feature(self, layer: int, seq_index: int, feature: int):
+        w = self.z_saes[layer].W_enc[:, feature].reshape(12, -1)
+        return self.get_head_seq_activations_for_vector(layer, seq_index, w)
+
+    def get_head_seq_lens_for_activations(self, feature_act, layer: int, seq_index: int, feature: int,
+                                          visualize=True, k=10) -> List[ComponentLensWithValue]:
+        feature_act = self.normalize_activations(feature_act)
+        values, indices = feature_act.topk(k=k)
+        runs = []
+        for index, value in zip(indices.tolist(), values.tolist()):
+            head, source = index // self.n_tokens, index % self.n_tokens
+            runs.append((ComponentLens(circuit_lens=self, component=CircuitComponent.ATTN_HEAD,
+                                       run_data={"layer": layer, "head": head, "source_index": int(source),
+                                                 "feature": feature, "destination_index": int(seq_index)}), value))
+        if visualize:
+            pprint([f"Head {r.run_data['head']} | Source: {r.run_data['source_index']} | Destination: "
+                    f"{r.run_data['destination_index']} | Contribution: {v * 100:.3g}%" for r, v in runs])
+        return runs
+
+    def get_head_seq_lens_for_z_feature(self, layer: int, seq_index: int, feature: int, visualize=True, k=10):
+        act = self.get_head_seq_activations_for_z_feature(layer, seq_index, feature)
+        return self.get_head_seq_lens_for_activations(act, layer, seq_index, feature, visualize=visualize, k=k)
+
+    def get_head_seq_lens_for_z_error(self, layer: int, seq_index: int, visualize=True, k=10):
+        seq_index = self.process_seq_index(seq_index)
+        err = self.get_active_features(seq_index).get_z_error(layer).reshape(12, -1)
+        act = self.get_head_seq_activations_for_vector(layer, seq_index, err)
+        return self.get_head_seq_lens_for_activations(act, layer, seq_index, -1, visualize=visualize, k=k)
+
+    def get_mlp_feature_lens_at_seq(self, layer: int, seq_index: int, feature: int, visualize=True, k=None):
+        seq_index = self.process_seq_index(seq_index)
+        af = self.get_active_features(seq_index)
+        vectors = af.get_vectors_before_comp("mlp", layer)
+        activation = self.normalize_activations(vectors @ self.mlp_transcoders[layer].W_enc[:, feature])
+        return self.get_next_lens_runs(af, activation, seq_index,
+                                       title=f"MLP Lens for Feature {feature} at '{self.get_str_token_at_seq(seq_index)}'/{seq_index}",
+                                       visualize=visualize, k=k)
+
+    def get_v_lens_activations(self, layer: int, head, seq_index: int, feature: int):
+        seq_index = self.process_seq_index(seq_index)
+        vectors = self.get_active_features(seq_index).get_vectors_before_comp("attn", layer)
+        d_head = self.model.cfg.d_head if hasattr(self.model.cfg, "d_head") else self.model.W_V.shape[-1]
+        eff_feature = self.z_saes[layer].W_enc[head * d_head:(head + 1) * d_head, feature]
+        return (vectors @ self.model.W_V[layer, head]) @ eff_feature
+
+    def get_v_lens_at_seq(self, layer: int, head: int, seq_index: int, feature: int, visualize=True, k=None):
+        seq_index = self.process_seq_index(seq_index)
+        af = self.get_active_features(seq_index)
+        activation = self.normalize_activations(self.get_v_lens_activations(layer, head, seq_index, feature))
+        return self.get_next_lens_runs(af, activation, seq_index,
+                                       title=f"V Lens | Layer {layer} | Head {head} | Feature {feature} at {seq_index}",
+                                       visualize=visualize, k=k)
+
+    def get_q_lens_activations(self, layer: int, head: int, source_index, destination_index):
+        source_index = self.process_seq_index(source_index)
+        destination_index = self.process_seq_index(destination_index)
+        vectors = self.get_active_features(destination_index).get_vectors_before_comp("attn", layer)
+        return (vectors @ self.model.W_Q[layer, head]) @ self.cache["k", layer][0, source_index, head]
+
+    def get_q_lens_on_head_seq(self, layer: int, head: int, source_index, destination_index, visualize=True, k=None):
+        source_index = self.process_seq_index(source_index)
+        destination_index = self.process_seq_index(destination_index)
+        af = self.get_active_features(destination_index)
+        activation = self.normalize_activations(self.get_q_lens_activations(layer, head, source_index, destination_index))
+        return self.get_next_lens_runs(af, activation, destination_index,
+                                       title=f"Q Lens | Layer {layer} | Head {head} | {source_index} -> {destination_index}",
+                                       visualize=visualize, k=k)
+
+    def get_k_lens_activations(self, layer: int, head: int, source_index, destination_index):
+        source_index = self.process_seq_index(source_index)
+        destination_index = self.process_seq_index(destination_index)
+        vectors = self.get_active_features(source_index).get_vectors_before_comp("attn", layer)
+        return (vectors @ self.model.W_K[layer, head]) @ self.cache["q", layer][0, destination_index, head]
+
+    def get_k_lens_on_head_seq(self, layer: int, head: int, source_index, destination_index, visualize=True, k=None):
+        source_index = self.process_seq_index(source_index)
+        destination_index = self.process_seq_index(destination_index)
+        af = self.get_active_features(source_index)
+        activation = self.normalize_activations(self.get_k_lens_activations(layer, head, source_index, destination_index))
+        return self.get_next_lens_runs(af, activation, source_index,
+                                       title=f"K Lens | Layer {layer} | Head {head} | {source_index} -> {destination_index}",
+                                       visualize=visualize, k=k)
+
+    # ------------------------------------------------------------------ input-x-gradient style pull-backs
+    def get_transcoder_ixg(self, transcoder, layer, seq_index, feature_vector, is_transcoder_post_ln=True,
+                           return_feature_activs=True):
+        """``(W_dec @ feature_vector) * feature_acts`` over all ``d_sae`` features (reference
+        :1138-1170).  The activations are sparse, so only the active features' ``W_dec`` rows are
+        read (``tsc_contrib_scores``) and scattered into a zero vector; inactive entries are
+        exactly 0 on both sides."""
+        if not is_transcoder_post_ln:
+            raise NotImplementedError("pre-LN transcoder inputs (resid_mid) are not cached in the batched pass")
+        seq_index = self.process_seq_index(seq_index)
+        if transcoder is not self.mlp_transcoders[layer]:
+            raise ValueError("get_transcoder_ixg expects the transcoder of the given layer")
+        feat, scores, count = self.contribution_scores("mlp", layer, feature_vector.reshape(1, -1), seq_index)
+        c = int(count[0])
+        d_sae = transcoder.W_enc.shape[1]
+        pulled = torch.zeros(d_sae, device=scores.device)
+        pulled[feat[0, :c].long()] = scores[0, :c, 0]
+        if not return_feature_activs:
+            return pulled
+        f_all, v_all, _, _, counts = self._sparse("mlp", layer)
+        acts = torch.zeros(d_sae, device=scores.device)
+        acts[f_all[seq_index, :counts[seq_index]].long()] = v_all[seq_index, :counts[seq_index]]
+        return pulled, acts
+
+    def get_ln_constant(self, vector, layer, token, is_ln2=False, recip=False):
+        x = self.cache[("resid_mid", layer) if is_ln2 else ("resid_pre", layer)][0, token]
+        y = self.cache[("normalized", layer, "ln2") if is_ln2 else ("normalized", layer, "ln1")][0, token]
+        if torch.dot(vector, x) == 0:
+            return torch.tensor(0.0, device=vector.device)
+        return torch.dot(vector, y) / torch.dot(vector, x) if not recip else torch.dot(vector, x) / torch.dot(vector, y)
+
+    def get_attn_head_contribs(self, layer: int, seq_index: int, feature_vector: torch.Tensor):
+        """Active z features of ``layer`` at ``seq_index`` as residual vectors ``[n_active, d_model]``
+        (the reference ignores ``feature_vector`` here too, :1189-1233)."""
+        seq_index = self.process_seq_index(seq_index)
+        zf, zv, _ = self._active("attn", layer, seq_index)
+        if zf.numel() == 0:
+            return torch.zeros(0, self.model.W_O.shape[-1], device=zv.device)
+        return self.z_saes[layer].device_dict().decode_rows(zf, zv) @ self._w_o_flat(layer)
+
+    def get_transcoder_contribs(self, layer: int, seq_index: int, feature_vector: torch.Tensor, k=5):
+        transcoder = self.mlp_transcoders[layer]
+        is_post_ln = "ln2" in transcoder.cfg.hook_point
+        if feature_vector.dim() == 2:
+            feature_vector = feature_vector.reshape(-1)
+        pulled, _ = self.get_transcoder_ixg(transcoder, layer, seq_index, feature_vector)
+        top_contribs, top_indices = torch.topk(pulled, k=k)
+        out = []
+        for contrib, index in zip(top_contribs, top_indices):
+            vector = transcoder.W_enc[:, index] * torch.dot(transcoder.W_dec[index], feature_vector)
+            if is_post_ln:
+                vector = vector * self.get_ln_constant(vector, layer, seq_index)  # ln1 constant, as the reference (:1269)
+            out.append((vector, layer, seq_index, index.item(), contrib.item()))
+        return out
+
+    def get_top_contribs(self, feature_vector: torch.Tensor, layer: int, seq_index: int, k=5):
+        """MLP-feature pull-backs of layers ``<= layer`` merged by score.  The reference's attention
+        branch (:1285-1310) unpacks a 2-D ``unravel_index`` into three names and raises for any
+        layer with an active z feature; that branch is therefore not reproduced."""
+        contribs = []
+        for cur in range(layer + 1):
+            contribs += self.get_transcoder_contribs(cur, seq_index, feature_vector, k=k)
+        scores = torch.tensor([c[4] for c in contribs])
+        _, top = torch.topk(scores, k=min(k, len(scores)))
+        return [contribs[i.item()] for i in top]

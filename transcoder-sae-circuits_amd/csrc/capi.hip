@@ -237,4 +237,17 @@ int tsc_contrib_scores(const tsc_dict_t *d, const int32_t *feat, const float *va
                               (hipStream_t)stream);
 }
 
+int tsc_project_features(const float *x, int64_t M, int d_in, const float *b_dec, const float *Pt,
+                         const float *bias, int F, int apply_relu, float *out, tsc_stream_t stream) {
+    if (M < 0 || F < 0) return tsc_fail(TSC_ERR_ARG, "negative shape");
+    if (M == 0 || F == 0) return TSC_OK;
+    if (d_in <= 0 || (d_in & 3) || d_in > 4096)
+        return tsc_fail(TSC_ERR_UNSUPPORTED, "d_in %d must be a multiple of 4 and at most 4096", d_in);
+    if (F > 64) return tsc_fail(TSC_ERR_UNSUPPORTED, "at most 64 features per call (got %d)", F);
+    if (!x || !Pt || !bias || !out) return tsc_fail(TSC_ERR_ARG, "null pointer");
+    if (!aligned16(x) || !aligned16(Pt) || !aligned16(b_dec))
+        return tsc_fail(TSC_ERR_ARG, "x, Pt and b_dec must be 16-byte aligned");
+    return tsc_launch_project(x, M, d_in, b_dec, Pt, bias, F, apply_relu, out, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -156,6 +156,49 @@ __global__ __launch_bounds__(256) void contrib_kernel(const float *W_dec, int d_
     }
 }
 
+// one wavefront per token row: the row (minus b_dec) is held in registers, each selected encoder
+// column (a contiguous row of Pt, L2-resident) is dotted against it
+__global__ __launch_bounds__(256) void project_kernel(const float *x, long long M, int d_in, const float *b_dec,
+                                                     const float *Pt, const float *bias, int F, int relu,
+                                                     float *out) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int chunks = d_in >> 2;  // <= 1024: up to 16 float4 per lane
+    for (long long m = wave; m < M; m += n_waves) {
+        f32x4 xr[16];
+        const f32x4 *src = (const f32x4 *)(x + m * d_in);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int ch = lane + 64 * j;
+            if (ch < chunks) {
+                xr[j] = src[ch];
+                if (b_dec) xr[j] -= ((const f32x4 *)b_dec)[ch];
+            } else {
+                xr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        for (int f = 0; f < F; ++f) {
+            const f32x4 *col = (const f32x4 *)(Pt + (long long)f * d_in);
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int ch = lane + 64 * j;
+                if (ch < chunks) {
+                    const f32x4 w = col[ch];
+                    part += xr[j].x * w.x + xr[j].y * w.y + xr[j].z * w.z + xr[j].w * w.w;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (lane == 0) {
+                float v = part + bias[f];
+                out[m * F + f] = (relu && v < 0.f) ? 0.f : v;
+            }
+        }
+    }
+}
+
 template <int NDIR>
 int launch_contrib(const float *W_dec, int d_out, const int *feat, const float *val, const int *count,
                    long long M, int max_active, const float *dirs, float *scores, hipStream_t stream) {
@@ -220,4 +263,15 @@ int tsc_launch_contrib(const float *W_dec, int d_out, const int *feat, const flo
     }
 #undef TSC_CASE
     return TSC_ERR_ARG;
+}
+
+int tsc_launch_project(const float *x, long long M, int d_in, const float *b_dec, const float *Pt,
+                       const float *bias, int F, int relu, float *out, hipStream_t stream) {
+    if (M <= 0 || F <= 0) return TSC_OK;
+    long long blocks = (M + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(project_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, M, d_in, b_dec, Pt, bias, F,
+                       relu, out);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
 }

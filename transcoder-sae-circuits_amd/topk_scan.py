@@ -1,0 +1,151 @@
+"""Streaming per-feature top-k of max-activating tokens over many dictionaries, single- or multi-GPU.
+
+This is the hot path itself (BASELINE.json north star): activations stream through
+``encode_topk`` (fused MFMA encode + top-k insert, no activation matrix in HBM), each rank owns a
+contiguous range of token rows, and the per-rank lists are combined with ONE all-gather + a local
+k-way merge at the end.  It replaces, for every feature at once, what the
+reference does one feature at a time in ``MaxActAnalysis.active_examples``
+(``src/max_act_analysis.py:197-255``) and what ``max_activating.main`` (``src/max_activating.py:97-122``)
+approximates by dumping dense activations.
+
+The numerical engine is pluggable only so that the multi-process plumbing can be exercised on CPU
+with ``gloo`` in the tests (which inject the oracle); the default and only product engine is HIP.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Iterable, Optional, Sequence, Tuple
+
+import torch
+
+import tsc_hip
+
+
+class HipTopkEngine:
+    """Running top-k of one dictionary on the GPU."""
+
+    def __init__(self, dictionary, k: int = 20, bf16: bool = False):
+        self.dictionary = dictionary
+        self.k = k
+        self.bf16 = bf16
+        self.state = dictionary.new_topk_state(k)
+
+    def update(self, x: torch.Tensor, token_id_base: int) -> None:
+        self.dictionary.encode_topk(x, token_id_base, self.state, bf16=self.bf16)
+
+    def finalize(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self.state.finalize()
+
+    @staticmethod
+    def merge(vals: torch.Tensor, idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        return tsc_hip.topk_merge(vals.contiguous(), idx.contiguous())
+
+
+def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous row range ``[start, stop)`` of rank ``rank``; the first ``n_rows % world`` ranks get
+    one extra row so the shards differ by at most one."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world {world}")
+    base, extra = divmod(n_rows, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def allgather_merge(vals: torch.Tensor, idx: torch.Tensor, merge: Callable, group=None):
+    """All ranks end with the identical merged lists.  The message is tiny (d_sae * k * 12 bytes per
+    rank), so one flat all-gather over xGMI is latency-bound; no ring tuning is needed."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    gv = torch.empty((world,) + tuple(vals.shape), dtype=vals.dtype, device=vals.device)
+    gi = torch.empty((world,) + tuple(idx.shape), dtype=idx.dtype, device=idx.device)
+    dist.all_gather_into_tensor(gv, vals.contiguous(), group=group)
+    dist.all_gather_into_tensor(gi, idx.contiguous(), group=group)
+    return merge(gv, gi)
+
+
+class MaxActSweep:
+    """Top-k lists for a set of named dictionaries fed with activation batches.
+
+    ``feed({name: x [tokens, d_in]}, token_id_base)`` may be called any number of times with
+    increasing, non-overlapping token-id ranges; ``result()`` returns ``{name: (vals [d_sae,k],
+    idx [d_sae,k])}``, merged across ranks when a process group is active."""
+
+    def __init__(self, dictionaries: Dict[str, object], k: int = 20, engine_factory: Optional[Callable] = None,
+                 distributed: Optional[bool] = None, group=None):
+        factory = engine_factory or (lambda d: HipTopkEngine(d, k))
+        self.engines = {name: factory(d) for name, d in dictionaries.items()}
+        self.k = k
+        self.group = group
+        if distributed is None:
+            import torch.distributed as dist
+
+            distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.distributed = distributed
+        self.tokens_seen = 0
+
+    def feed(self, acts: Dict[str, torch.Tensor], token_id_base: int) -> None:
+        n = None
+        for name, x in acts.items():
+            x2 = x.reshape(-1, x.shape[-1])
+            n = x2.shape[0] if n is None else n
+            if x2.shape[0] != n:
+                raise ValueError("all dictionaries must be fed the same number of token rows per call")
+            self.engines[name].update(x2, token_id_base)
+        self.tokens_seen += n or 0
+
+    def result(self) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
+        out = {}
+        for name, eng in self.engines.items():
+            vals, idx = eng.finalize()
+            if self.distributed:
+                vals, idx = allgather_merge(vals, idx, eng.merge, self.group)
+            out[name] = (vals, idx)
+        return out
+
+
+def hook_names(kind: str, layer: int, encoder=None) -> str:
+    if kind == "attn":
+        return f"blocks.{layer}.attn.hook_z"  # max_act_analysis.py:207
+    return getattr(getattr(encoder, "cfg", None), "hook_point", None) or f"blocks.{layer}.ln2.hook_normalized"
+
+
+def sweep_model(model, tokens: torch.Tensor, z_saes: Optional[Sequence] = None, transcoders: Optional[Sequence] = None,
+                layers: Optional[Iterable[int]] = None, k: int = 20, batch_size: int = 128,
+                rank: int = 0, world: int = 1, engine_factory: Optional[Callable] = None, distributed: Optional[bool] = None):
+    """Run ``model`` over ``tokens [n_seq, n_pos]`` and keep, for every feature of every given
+    dictionary, the ``k`` max-activating tokens.  Token ids are ``seq * n_pos + pos`` (global), rank
+    ``rank`` of ``world`` processes rows ``shard_rows(n_seq, rank, world)``.  Returns
+    ``{"z_{L}" / "mlp_{L}": (vals, idx)}`` -- the keys of ``get_activation_dictionary``
+    (reference src/max_activating.py:55,63)."""
+    n_seq, n_pos = tokens.shape
+    dicts, hooks = {}, {}
+    n_layers = len(z_saes) if z_saes is not None else len(transcoders)
+    layers = list(range(n_layers)) if layers is None else list(layers)
+    for l in layers:
+        if z_saes is not None:
+            dicts[f"z_{l}"] = z_saes[l]
+            hooks[f"z_{l}"] = hook_names("attn", l)
+        if transcoders is not None:
+            dicts[f"mlp_{l}"] = transcoders[l]
+            hooks[f"mlp_{l}"] = hook_names("mlp", l, transcoders[l])
+    sweep = MaxActSweep(dicts, k=k, engine_factory=engine_factory, distributed=distributed)
+    start, stop = shard_rows(n_seq, rank, world)
+    wanted = sorted(set(hooks.values()))
+    stop_at = max(layers) + 1
+    for s in range(start, stop, batch_size):
+        rows = tokens[s:min(s + batch_size, stop)]
+        with torch.no_grad():
+            _, cache = model.run_with_cache(rows, stop_at_layer=stop_at, names_filter=wanted)
+        acts = {}
+        for name, hook in hooks.items():
+            a = cache[hook]
+            acts[name] = a.reshape(a.shape[0] * a.shape[1], -1)  # "b pos n d -> (b pos) (n d)", max_act_analysis.py:227
+        sweep.feed(acts, s * n_pos)
+    return sweep.result()
+
+
+def unravel_token_ids(idx: torch.Tensor, n_pos: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Global token id -> ``(sequence, position)``; padding ids (-1) map to ``(-1, -1)``."""
+    seq = torch.where(idx >= 0, torch.div(idx, n_pos, rounding_mode="floor"), idx)
+    pos = torch.where(idx >= 0, idx % n_pos, idx)
+    return seq, pos

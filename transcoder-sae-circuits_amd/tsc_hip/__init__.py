@@ -41,6 +41,8 @@ _SIGNATURES = {
                                      _c.c_void_p, _c.c_void_p]),
     "tsc_contrib_scores": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int,
                                       _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "tsc_project_features": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                        _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -247,3 +249,27 @@ def topk_merge(vals: torch.Tensor, idx: torch.Tensor) -> Tuple[torch.Tensor, tor
         _check(lib().tsc_topk_merge(vals.data_ptr(), idx.data_ptr(), n_lists, d_sae, k, ov.data_ptr(), oi.data_ptr(),
                                     _stream()))
     return ov, oi
+
+
+def project_features(x: torch.Tensor, Pt: torch.Tensor, bias: torch.Tensor, b_dec: Optional[torch.Tensor] = None,
+                     relu: bool = False) -> torch.Tensor:
+    """``act((x - b_dec) @ Pt.T + bias)`` for a handful of encoder columns ``Pt [F, d_in]`` ->
+    ``[M, F]``; features are processed 64 per launch."""
+    x2 = _dev(x, torch.float32, "x").reshape(-1, x.shape[-1])
+    Pt = _dev(Pt, torch.float32, "Pt")
+    bias = _dev(bias, torch.float32, "bias")
+    if b_dec is not None:
+        _dev(b_dec, torch.float32, "b_dec")
+    m, d_in = x2.shape
+    n_feat = Pt.shape[0]
+    parts = []
+    with torch.cuda.device(x.device):
+        for s in range(0, n_feat, 64):
+            pt = Pt[s:s + 64].contiguous()
+            bs = bias[s:s + 64].contiguous()
+            out = torch.empty(m, pt.shape[0], dtype=torch.float32, device=x.device)
+            _check(lib().tsc_project_features(x2.data_ptr(), m, d_in, b_dec.data_ptr() if b_dec is not None else None,
+                                              pt.data_ptr(), bs.data_ptr(), pt.shape[0], int(relu), out.data_ptr(),
+                                              _stream()))
+            parts.append(out)
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
