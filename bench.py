@@ -132,15 +132,11 @@ def main():
     def finish():
         outs = [st.finalize() for st in states]
         if world > 1:
-            import torch.distributed as dist
+            from topk_scan import allgather_merge
 
             merged = []
             for vals, idx in outs:
-                gv = torch.empty(world, *vals.shape, dtype=vals.dtype, device=device)
-                gi = torch.empty(world, *idx.shape, dtype=idx.dtype, device=device)
-                dist.all_gather_into_tensor(gv, vals)
-                dist.all_gather_into_tensor(gi, idx)
-                merged.append(tsc_hip.topk_merge(gv, gi))
+                merged.append(allgather_merge(vals, idx, tsc_hip.topk_merge))
             outs = merged
         return outs
 

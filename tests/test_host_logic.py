@@ -1,0 +1,136 @@
+"""CPU tests of the host-side logic: ActiveFeatures index algebra against the reference's golden
+rankings, row sharding, and the world_size-2 token-sharded sweep over ``gloo`` (the oracle is injected
+as the numerical engine HERE ONLY, to exercise the multi-process plumbing without a GPU)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import golden_inputs as gi
+from oracle import lens_ref as L
+
+
+def _active_features_from_oracle(pos):
+    from circuit_lens import ActiveFeatures
+
+    g3, g4, model, z_w, t_w = gi.lens_inputs()
+    tokens = model.to_tokens(gi.PROMPT)
+    _, cache = model.run_with_cache(tokens)
+    vectors, values, features, keys = L.active_features_ref(model, cache, z_w, t_w, pos)
+    return ActiveFeatures(vectors=vectors, values=values, features=features, keys=keys), g3, g4, model, tokens
+
+
+def test_active_features_index_algebra_matches_reference_rankings():
+    af, g3, g4, model, tokens = _active_features_from_oracle(12)
+    keys = af.keys
+    n_layers = len(keys)
+    assert af.get_total_auxilary_features() == 2 + 5 * n_layers
+    assert af.get_total_active_features() == sum(k["attn"] + k["mlp"] for k in keys)
+    assert af.vectors.shape[0] == af.get_total_auxilary_features() + af.get_total_active_features()
+    assert af.get_attn_start_index(0) == 2
+    assert af.get_mlp_start_index(0) == 2 + 3 + keys[0]["attn"]
+    assert af.get_attn_start_index(1) == 2 + 5 + keys[0]["attn"] + keys[0]["mlp"]
+    assert af.get_vectors_before_comp("attn", n_layers).shape[0] == af.vectors.shape[0]
+    assert af.get_attn_feature_vectors(1).shape[0] == keys[1]["attn"]
+    assert af.get_mlp_feature_vectors(2).shape[0] == keys[2]["mlp"]
+    assert af.max_active_features == max(max(k["attn"], k["mlp"]) for k in keys)
+    # features are -1 exactly on auxiliary rows
+    for i in range(af.vectors.shape[0]):
+        kind, layer = af.classify_row(i)
+        assert (int(af.features[i]) >= 0) == (kind in ("z_feature", "mlp_feature"))
+    # rankings produced by the reference's get_top_k_features (incl. its stop at embed/pos_embed)
+    tok = int(tokens[0, 13])
+    raw = L.unembed_lens_raw_ref(af.vectors, model.W_U, tok)
+    top = af.get_top_k_features(L.normalize_ref(raw), k=10)
+    assert [[gi.COMPONENT_IDS.index(c), l, f] for c, l, f, _ in top] == g4["unembed_top_ids"].tolist()
+    assert np.allclose([v for *_, v in top], g4["unembed_top_vals"], atol=1e-5)
+    masked = raw.clone()
+    masked[:2] = -1e9
+    top = af.get_top_k_features(masked, k=40)
+    assert [[gi.COMPONENT_IDS.index(c), l, f] for c, l, f, _ in top] == g4["topk_masked_ids"].tolist()
+    labels = af.get_top_k_labels(masked, k=3)
+    assert len(labels) == 3 and "Layer" in labels[0]
+
+
+def test_component_lens_tuple_ids_round_trip():
+    from circuit_lens import CircuitComponent, ComponentLens
+
+    for tid in [(CircuitComponent.UNEMBED, 3, 17), (CircuitComponent.UNEMBED_AT_TOKEN, 4),
+                (CircuitComponent.ATTN_HEAD, 2, 5, 1, 9, 300), (CircuitComponent.MLP_FEATURE, 1, 7, 42),
+                (CircuitComponent.Z_SAE_ERROR, 0, 2, -1)]:
+        lens = ComponentLens.init_from_tuple_id(tid, circuit_lens=None)
+        assert lens.tuple_id == tid
+    assert ComponentLens(None, CircuitComponent.EMBED, {"layer": 0, "seq_index": 1, "feature": -1})() == ([], None)
+    assert ComponentLens(None, CircuitComponent.UNEMBED, {"seq_index": 1, "token_id": 2}).feature == -1
+
+
+def test_shard_rows_partitions_exactly():
+    from topk_scan import shard_rows, unravel_token_ids
+
+    for n, world in ((10, 3), (8, 8), (5, 8), (25600, 8), (0, 2)):
+        spans = [shard_rows(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_rows(4, 4, 4)
+    seq, pos = unravel_token_ids(torch.tensor([[0, 129, -1]]), 128)
+    assert seq.tolist() == [[0, 1, -1]] and pos.tolist() == [[0, 1, -1]]
+
+
+class _OracleEngine:
+    """Test-only engine: the CPU oracle behind the product's engine interface."""
+
+    def __init__(self, w, k):
+        from oracle.topk_ref import empty_state
+
+        self.w, self.k = w, k
+        self.state = empty_state(w["W_enc"].shape[1], k)
+
+    def update(self, x, base):
+        from oracle.topk_ref import topk_stream_ref
+
+        self.state = topk_stream_ref(x, self.w, k=self.k, token_id_base=base, state=self.state)
+
+    def finalize(self):
+        return self.state
+
+    @staticmethod
+    def merge(vals, idx):
+        from oracle.topk_ref import topk_merge_ref
+
+        return topk_merge_ref([(vals[i], idx[i]) for i in range(vals.shape[0])], k=vals.shape[-1])
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from replay_model import ReplayModel
+    from topk_scan import sweep_model
+
+    g, w, xs, n_seq, n_pos = gi.g2_inputs()
+    model = ReplayModel(xs, n_seq, n_pos)
+    dummy = type("D", (), {"w": w, "cfg": type("C", (), {"hook_point": "blocks.0.ln2.hook_normalized"})()})()
+    res = sweep_model(model, model.token_matrix(), transcoders=[dummy], layers=[0], k=20, batch_size=5,
+                      rank=rank, world=world, engine_factory=lambda d: _OracleEngine(d.w, 20))
+    vals, idx = res["mlp_0"]
+    torch.save((vals, idx), os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_token_sharded_sweep_two_ranks_gloo(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    g = gi.load("g2_topk.npz")
+    outs = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    for vals, idx in outs:  # every rank ends with the identical, complete answer
+        assert np.array_equal(idx.numpy(), g["idx"].astype(np.int64))
+        assert np.allclose(vals.numpy(), g["vals"], rtol=1e-4, atol=1e-5)

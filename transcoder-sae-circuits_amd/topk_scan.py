@@ -56,11 +56,12 @@ def allgather_merge(vals: torch.Tensor, idx: torch.Tensor, merge: Callable, grou
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    gv = torch.empty((world,) + tuple(vals.shape), dtype=vals.dtype, device=vals.device)
-    gi = torch.empty((world,) + tuple(idx.shape), dtype=idx.dtype, device=idx.device)
+    d_sae, k = vals.shape
+    gv = torch.empty(world * d_sae, k, dtype=vals.dtype, device=vals.device)  # concatenated along dim 0:
+    gi = torch.empty(world * d_sae, k, dtype=idx.dtype, device=idx.device)    # the layout both RCCL and gloo accept
     dist.all_gather_into_tensor(gv, vals.contiguous(), group=group)
     dist.all_gather_into_tensor(gi, idx.contiguous(), group=group)
-    return merge(gv, gi)
+    return merge(gv.view(world, d_sae, k), gi.view(world, d_sae, k))
 
 
 class MaxActSweep:
