@@ -45,3 +45,14 @@ n = args.launches - args.launches // 2
 ms = e0.elapsed_time(e1) / n
 print(f"{args.mode} d_sae={args.d_sae} tokens={args.tokens}: {ms:.3f} ms/launch, "
       f"{2.0 * 768 * args.d_sae * args.tokens / ms / 1e9:.1f} TFLOP/s")
+lib = tsc_hip.lib()
+if hasattr(lib, "tsc_debug_read_stamps"):
+    import ctypes
+    buf = (ctypes.c_ulonglong * 16)()
+    lib.tsc_debug_read_stamps(buf)
+    names = ["loop top", "gload issue", "frag1+mfma16 (kk0)", "frag2+mfma16 (kk1)", "frag3+mfma16 (kk2)", "sstore",
+             "mfma8 (kk3a)", "barrier", "frag0'+mfma8 (kk3b)", "epilogue"]
+    tot = sum(buf[i] for i in range(10))
+    print("stamps of block 0 / wave 0 over its lifetime in the LAST launch (cycles, share):")
+    for i, n in enumerate(names):
+        print(f"  {n:24s} {buf[i]:12d}  {100.0 * buf[i] / max(tot, 1):5.1f}%")

@@ -19,22 +19,7 @@ int tsc_fail(int code, const char *fmt, ...) {
 
 namespace {
 
-constexpr int TILE_N = 128, TILE_M = 128;
-constexpr int RESIDENT_WGS = 512;  // 256 CUs x 2 workgroups (LDS-limited)
-
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
-// number of token-tile groups per column tile such that the grid is a whole number of waves of
-// resident workgroups (every workgroup does the same amount of work, so a ragged last wave of
-// workgroups is pure idle time)
-int balanced_split(int n_tiles_n, long long n_tiles_m, int cap) {
-    if (cap > n_tiles_m) cap = (int)(n_tiles_m < 1 ? 1 : n_tiles_m);
-    for (int s = 1; s <= cap; ++s)
-        if (((long long)n_tiles_n * s) % RESIDENT_WGS == 0) return s;
-    int s = (2 * RESIDENT_WGS + n_tiles_n - 1) / n_tiles_n;
-    if (s < 1) s = 1;
-    return s > cap ? cap : s;
-}
 
 int check_dict_x(const tsc_dict_t *d, const float *x, int64_t M) {
     if (!d) return tsc_fail(TSC_ERR_ARG, "null dictionary handle");
@@ -49,8 +34,7 @@ EncodeArgs base_args(const tsc_dict_t *d, const float *x, int64_t M) {
     memset(&a, 0, sizeof(a));
     a.x = x; a.W = d->W_enc; a.b_enc = d->b_enc; a.b_dec = d->b_dec;
     a.M = M; a.K = d->d_in; a.N = d->d_sae;
-    a.n_tiles_n = (d->d_sae + TILE_N - 1) / TILE_N;
-    a.m_split = 1;
+    a.m_split = 0;  // the launcher picks the tile geometry and the balanced split
     return a;
 }
 
@@ -120,13 +104,12 @@ int tsc_encode_dense(const tsc_dict_t *d, const float *x, int64_t M, float *out,
     if (!out) return tsc_fail(TSC_ERR_ARG, "null output pointer");
     EncodeArgs a = base_args(d, x, M);
     a.out = out;
-    a.m_split = balanced_split(a.n_tiles_n, (M + TILE_M - 1) / TILE_M, 64);
     return run_encode(d, TSC_MODE_DENSE, a, (hipStream_t)stream);
 }
 
 int tsc_topk_recommended_slots(int d_sae) {
     if (d_sae <= 0) return 1;
-    return balanced_split((d_sae + TILE_N - 1) / TILE_N, 1 << 30, 16);
+    return tsc_encode_f32_recommended_slots(d_sae);
 }
 
 static int check_state(const tsc_topk_state_t *s) {
@@ -190,7 +173,6 @@ int tsc_encode_sparse(const tsc_dict_t *d, const float *x, int64_t M, int max_ac
     TSC_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)M * sizeof(int32_t), s));
     EncodeArgs a = base_args(d, x, M);
     a.sp_feat = feat; a.sp_val = val; a.sp_count = count; a.max_active = max_active;
-    a.m_split = balanced_split(a.n_tiles_n, (M + TILE_M - 1) / TILE_M, 64);
     rc = run_encode(d, TSC_MODE_SPARSE, a, s);
     if (rc) return rc;
     return tsc_launch_sparse_sort(feat, val, count, M, max_active, s);

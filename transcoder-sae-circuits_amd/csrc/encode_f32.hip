@@ -3,14 +3,14 @@
 //   acts[m, n] = relu( sum_k (x[m,k] - b_dec[k]) * W_enc[k,n] + b_enc[n] )
 //
 // replaces SparseTranscoder.encode (reference src/mlp_transcoder.py:194-213) and ZSAE.encode
-// (src/z_sae.py:73-77).  One workgroup (4 waves, one per SIMD; two workgroups per CU) owns one
-// 128-feature column tile of the dictionary and walks a strided set of 128-token row tiles, so the
-// per-feature state of the fused top-k epilogue stays with that workgroup for the whole launch.
+// (src/z_sae.py:73-77).  One workgroup (4 waves, one per SIMD) owns one column tile of the
+// dictionary and walks a strided set of token row tiles, so the per-feature state of the fused top-k
+// epilogue stays with that workgroup for the whole launch.
 //
 //   main loop : K in steps of 32; x and W_enc tiles prefetched global->VGPR during the MFMAs of the
 //               previous step, written to a double-buffered LDS image after them (one barrier per
 //               step); `x - b_dec` is applied while staging (the reference subtracts before the
-//               contraction, mlp_transcoder.py:200-202).  Each wave computes 64x64 outputs as 2x2
+//               contraction, mlp_transcoder.py:200-202).  Each wave computes WMB x WNB
 //               v_mfma_f32_32x32x2_f32 accumulators: exact fp32, one rounding per product.
 //   DENSE     : + b_enc, ReLU, streaming store of the [M, d_sae] matrix.
 //   TOPK      : + b_enc, compare against the feature's current k-th best; survivors go through an
@@ -19,29 +19,50 @@
 //               all features at once.)
 //   SPARSE    : + b_enc, every activation > 0 is appended to its token's (feature, value) list
 //               (circuit_lens.py:612-614 / 647-649 before the sort).
+//
+// Two tile geometries are compiled (Cfg): 128x128 per workgroup with two workgroups per CU, and
+// 256x256 with one workgroup per CU holding 256 accumulator registers per lane.  On this pipe the
+// VALU shares the SIMD's issue with the fp32 MFMA and a wave issues in order, so what decides the
+// rate is the number of non-MFMA instructions per MFMA; the large tile halves it.
+#include <cstdlib>
+
 #include "tsc_internal.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
+constexpr int BK = 32, NT = 256;
 constexpr int LDA = BK + 4;  // 144-byte rows: ds_read_b128 of 16 consecutive rows hits 16 distinct slots
-constexpr int LDB = BN;      // [k][n] image, read one dword per lane (32 consecutive n: conflict-free)
 constexpr int QCAP = 512;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+template <int WMB_, int WNB_, int OCC_>
+struct Cfg {
+    static constexpr int WMB = WMB_, WNB = WNB_, OCC = OCC_;  // 32x32 blocks per wave; workgroups per CU
+    static constexpr int BM = 2 * WMB * 32, BN = 2 * WNB * 32;  // 4 waves as 2 x 2
+    static constexpr int A_LD = BM / 32;                      // float4 loads of x per thread and k-step
+    static constexpr int B_TPR = BN / 4;                      // threads per W row
+    static constexpr int B_RPP = NT / B_TPR;                  // W rows per pass
+    static constexpr int B_LD = BK / B_RPP;                   // float4 loads of W per thread and k-step
+    static_assert(BN <= 256, "one owner thread per feature, column index packed in 8 bits");
+    static_assert(BM <= 256, "row index packed in 8 bits");
+};
+typedef Cfg<2, 2, 2> CfgSmall;
+typedef Cfg<4, 4, 1> CfgLarge;
+
+template <class C>
 struct __attribute__((aligned(16))) Smem {
-    float A[2][BM * LDA];
-    float B[2][BK * LDB];
-    float thr[BN];
+    float A[2][C::BM * LDA];
+    float B[2][BK * C::BN];  // [k][n] image, read one dword per lane (32 consecutive n: conflict-free)
+    float thr[C::BN];
     float q_val[QCAP];
     int q_loc[QCAP];  // (row in tile << 8) | column in tile
     // per-feature list state, owned by thread t < BN: entries held, and the lowest-ranked entry
-    long long f_worst_id[BN];
-    float f_worst_v[BN];
-    int f_worst_pos[BN];
-    int f_cnt[BN];
+    long long f_worst_id[C::BN];
+    float f_worst_v[C::BN];
+    int f_worst_pos[C::BN];
+    int f_cnt[C::BN];
     int q_count;
     int pad[3];
 };
@@ -51,16 +72,23 @@ __device__ __forceinline__ bool ranks_below(float v, long long id, float w, long
     return v < w || (v == w && id > wid);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
-    __shared__ Smem sm;
+#ifdef TSC_NO_PIN
+#define TSC_PIN
+#else
+#define TSC_PIN __builtin_amdgcn_sched_barrier(0);
+#endif
+
+template <class C, int MODE, bool KALIGNED>
+__global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs a) {
+    constexpr int WMB = C::WMB, WNB = C::WNB, BM = C::BM, BN = C::BN;
+    __shared__ Smem<C> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int wm0 = (wave >> 1) * (WMB * 32), wn0 = (wave & 1) * (WNB * 32);
 
     // Blocks b and b+8 share an XCD (round-robin dispatch): give every XCD its own column tiles
-    // so the 393-KB W_enc slabs of the tiles resident on one XCD stay in that XCD's 4-MiB L2, and
-    // the token tiles they stream are shared.  A speed heuristic only.
+    // so the W_enc slabs of the tiles resident on one XCD stay in that XCD's 4-MiB L2, and the
+    // token tiles they stream are shared.  A speed heuristic only.
     int nt, slot;
     {
         const int w = blockIdx.x;
@@ -77,18 +105,18 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
     const long long n_mtiles = (a.M + BM - 1) / BM;
     const int nk = (a.K + BK - 1) / BK;
 
-    // epilogue constants of this lane: two features (column li of the two 32-wide blocks)
-    float be[2];
-    bool nok[2];
+    // epilogue constants of this lane: WNB features (column li of each 32-wide block)
+    float be[WNB];
+    bool nok[WNB];
 #pragma unroll
-    for (int bn = 0; bn < 2; ++bn) {
+    for (int bn = 0; bn < WNB; ++bn) {
         const int n = n0 + wn0 + bn * 32 + li;
         nok[bn] = n < a.N;
         be[bn] = nok[bn] ? a.b_enc[n] : 0.f;
     }
 
     // TOPK: thread t < BN owns feature n0 + t of list set `slot`; its view of the list (kept in
-    // LDS, not registers: the main loop is register-bound) is rebuilt from HBM at start-up
+    // LDS, not registers) is rebuilt from HBM at start-up
     if (MODE == TSC_MODE_TOPK) {
         if (tid < BN) {
             int cnt = 0, wpos = 0;
@@ -125,63 +153,85 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
         __syncthreads();
     }
 
-    f32x4 ra[4], rb[4], rbd;
+    f32x4 ra[C::A_LD], rb[C::B_LD], rbd;
     const int a_row = tid >> 3, a_col = (tid & 7) * 4;
-    const int b_row = tid >> 5, b_col = (tid & 31) * 4;
+    const int b_row = tid / C::B_TPR, b_col = (tid % C::B_TPR) * 4;
 
     // Loads are unconditional from clamped (always valid) addresses: a bounds-checked
     // "load or zero" makes hipcc branch around every load and drain the queue per element.
     // Rows past M and columns past N then hold finite copies of real data and are masked in the
     // epilogue; k past K is zeroed on the W side while staging (so x garbage there multiplies 0).
-    // Addresses are a wave-uniform 64-bit base plus a 32-bit lane offset (saddr form): 64-bit
-    // per-lane pointers would cost 2 VGPRs per load in a loop that has none to spare.
+    // Addresses are a wave-uniform 64-bit base (advanced by scalar adds per k-step) plus a 32-bit
+    // lane offset that is constant per token tile: vector-side address arithmetic per k-step costs
+    // matrix throughput directly.
     const int nc = n0 + b_col < a.N - 4 ? n0 + b_col : a.N - 4;
-    auto gload = [&](long long m0, int k0) {
-        const int kc = k0 + a_col < a.K - 4 ? k0 + a_col : a.K - 4;
-        rbd = *(const f32x4 *)(a.b_dec + kc);
-        const char *xt = (const char *)(a.x + m0 * a.K);
+    unsigned a_voff[C::A_LD], b_voff[C::B_LD];
+    const unsigned bd_voff = (unsigned)a_col * 4u;
+#pragma unroll
+    for (int i = 0; i < C::B_LD; ++i)
+        b_voff[i] = ((unsigned)(b_row + C::B_RPP * i) * (unsigned)a.N + (unsigned)nc) * 4u;
+    auto set_tile = [&](long long m0) {  // lane offsets of the x rows of the tile being prefetched
         const long long rows_left = a.M - m0;  // >= 1
         const int rmax = rows_left > BM ? BM - 1 : (int)rows_left - 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < C::A_LD; ++i) {
             const int r = a_row + 32 * i < rmax ? a_row + 32 * i : rmax;
-            ra[i] = *(const f32x4 *)(xt + (unsigned)(r * a.K + kc) * 4u);
+            a_voff[i] = (unsigned)(r * a.K + a_col) * 4u;
         }
-        const char *wt = (const char *)a.W;
+    };
+    auto gload = [&](long long m0, int k0) {
+        if (KALIGNED) {
+            const char *xt = (const char *)(a.x + m0 * a.K + k0);
+            const char *wt = (const char *)(a.W + (long long)k0 * a.N);
+            rbd = *(const f32x4 *)((const char *)(a.b_dec + k0) + bd_voff);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int kr = k0 + b_row + 8 * i;
-            kr = kr < a.K ? kr : a.K - 1;
-            rb[i] = *(const f32x4 *)(wt + ((size_t)kr * a.N + nc) * 4u);
+            for (int i = 0; i < C::A_LD; ++i) ra[i] = *(const f32x4 *)(xt + a_voff[i]);
+#pragma unroll
+            for (int i = 0; i < C::B_LD; ++i) rb[i] = *(const f32x4 *)(wt + b_voff[i]);
+        } else {
+            const int kc = k0 + a_col < a.K - 4 ? k0 + a_col : a.K - 4;
+            rbd = *(const f32x4 *)(a.b_dec + kc);
+            const char *xt = (const char *)(a.x + m0 * a.K);
+#pragma unroll
+            for (int i = 0; i < C::A_LD; ++i)
+                ra[i] = *(const f32x4 *)(xt + a_voff[i] + (unsigned)(kc - a_col) * 4u);
+            const char *wt = (const char *)a.W;
+#pragma unroll
+            for (int i = 0; i < C::B_LD; ++i) {
+                int kr = k0 + b_row + C::B_RPP * i;
+                kr = kr < a.K ? kr : a.K - 1;
+                rb[i] = *(const f32x4 *)(wt + ((size_t)kr * a.N + nc) * 4u);
+            }
         }
     };
     auto sstore = [&](int buf, int k0) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < C::A_LD; ++i)
             *(f32x4 *)&sm.A[buf][(a_row + 32 * i) * LDA + a_col] = ra[i] - rbd;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *(f32x4 *)&sm.B[buf][(b_row + 8 * i) * LDB + b_col] = (k0 + b_row + 8 * i < a.K) ? rb[i] : z;
+        for (int i = 0; i < C::B_LD; ++i)
+            *(f32x4 *)&sm.B[buf][(b_row + C::B_RPP * i) * BN + b_col] =
+                (KALIGNED || k0 + b_row + C::B_RPP * i < a.K) ? rb[i] : z;
     };
 
     // Fragments of one group of 8 k (4 MFMA k-steps): MFMA step s contracts k = 8*kk + 4*lh + s
     // (lane half lh).  Any bijection works as long as A and B agree, and this one makes the A
     // fragment a single 16-byte LDS read.
     struct Frag {
-        f32x4 af[2], bf[2];
+        f32x4 af[WMB], bf[WNB];
     };
     auto ldfrag = [&](int buf, int kk, Frag &f) {
         const float *As = sm.A[buf];
         const float *Bs = sm.B[buf];
 #pragma unroll
-        for (int bm = 0; bm < 2; ++bm)
+        for (int bm = 0; bm < WMB; ++bm)
             f.af[bm] = *(const f32x4 *)&As[(wm0 + bm * 32 + li) * LDA + kk * 8 + lh * 4];
 #pragma unroll
-        for (int bn = 0; bn < 2; ++bn)
+        for (int bn = 0; bn < WNB; ++bn)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                f.bf[bn][s] = Bs[(kk * 8 + lh * 4 + s) * LDB + wn0 + bn * 32 + li];
+                f.bf[bn][s] = Bs[(kk * 8 + lh * 4 + s) * BN + wn0 + bn * 32 + li];
     };
 
     // The workgroup's work is one continuous stream of k-steps over all its token tiles: the
@@ -190,6 +240,7 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
     int parity = 0;
     long long mt = slot;
     if (mt < n_mtiles) {
+        set_tile(mt * BM);
         gload(mt * BM, 0);
         sstore(0, 0);
     }
@@ -199,17 +250,17 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
 
     for (; mt < n_mtiles; mt += a.m_split) {
         const long long m0 = mt * BM;
-        f32x16 acc[2][2];
+        f32x16 acc[WMB][WNB];
 #pragma unroll
-        for (int bm = 0; bm < 2; ++bm)
+        for (int bm = 0; bm < WMB; ++bm)
 #pragma unroll
-            for (int bn = 0; bn < 2; ++bn)
+            for (int bn = 0; bn < WNB; ++bn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[bm][bn][r] = 0.f;
 
-#define TSC_MFMA(FR, S0, S1)                                                                   \
-    _Pragma("unroll") for (int s = S0; s < S1; ++s) _Pragma("unroll") for (int bm = 0; bm < 2; ++bm) \
-        _Pragma("unroll") for (int bn = 0; bn < 2; ++bn) acc[bm][bn] =                         \
+#define TSC_MFMA(FR, S0, S1)                                                                     \
+    _Pragma("unroll") for (int s = S0; s < S1; ++s) _Pragma("unroll") for (int bm = 0; bm < WMB; ++bm) \
+        _Pragma("unroll") for (int bn = 0; bn < WNB; ++bn) acc[bm][bn] =                         \
             __builtin_amdgcn_mfma_f32_32x32x2f32(FR.af[bm][s], FR.bf[bn][s], acc[bm][bn], 0, 0, 0);
 
         for (int kt = 0; kt < nk; ++kt) {
@@ -218,50 +269,67 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
             const long long next_m0 = last_k ? (mt + a.m_split) * BM : m0;
             const int next_k0 = last_k ? 0 : (kt + 1) * BK;
             const bool more = !last_k || mt + a.m_split < n_mtiles;
-#ifndef TSC_EXP_NOLOAD
+#ifndef TSC_ABL_NOGLOAD
+            if (last_k && more) set_tile(next_m0);
             if (more) gload(next_m0, next_k0);
 #endif
-            ldfrag(parity, 1, G);
-            TSC_MFMA(F, 0, 4)
-            ldfrag(parity, 2, F);
-            TSC_MFMA(G, 0, 4)
-            ldfrag(parity, 3, G);
-            TSC_MFMA(F, 0, 4)
+            // The order below is pinned with sched_barrier(0): left alone, hipcc sinks every fragment
+            // read to just before its first use and hoists the barrier above the MFMAs meant to cover it.
+#ifdef TSC_ABL_NOFRAG  // timing experiments only: results are garbage
+#define TSC_LDFRAG(b, k, f) { _Pragma("unroll") for (int q_ = 0; q_ < WMB; ++q_) asm volatile("" : "+v"(f.af[q_])); \
+                              _Pragma("unroll") for (int q_ = 0; q_ < WNB; ++q_) asm volatile("" : "+v"(f.bf[q_])); }
+#else
+#define TSC_LDFRAG(b, k, f) ldfrag(b, k, f);
+#endif
+            TSC_PIN TSC_LDFRAG(parity, 1, G)
+            TSC_PIN TSC_MFMA(F, 0, 4)
+            TSC_PIN TSC_LDFRAG(parity, 2, F)
+            TSC_PIN TSC_MFMA(G, 0, 4)
+            TSC_PIN TSC_LDFRAG(parity, 3, G)
+            TSC_PIN TSC_MFMA(F, 0, 4)
             // stage the prefetched k-step into the other buffer (free since the last barrier),
             // cover the LDS write latency and the barrier with the first half of the last group,
             // and the first fragment read of the new buffer with the second half
-            if (more) sstore(parity ^ 1, next_k0);
-            TSC_MFMA(G, 0, 2)
-            __syncthreads();
-            if (more) ldfrag(parity ^ 1, 0, F);
-            TSC_MFMA(G, 2, 4)
+#ifndef TSC_ABL_NOSSTORE
+            TSC_PIN if (more) sstore(parity ^ 1, next_k0);
+#endif
+            TSC_PIN TSC_MFMA(G, 0, 2)
+#ifndef TSC_ABL_NOBARRIER
+            TSC_PIN __syncthreads();
+#endif
+            TSC_PIN if (more) { TSC_LDFRAG(parity ^ 1, 0, F) }
+            TSC_PIN TSC_MFMA(G, 2, 4)
+            TSC_PIN
             parity ^= 1;
         }
 #undef TSC_MFMA
 
         // ---------------------------------------------------------------- epilogues
         // C layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-        // The lane's row/column bases are made opaque once per tile: otherwise hipcc hoists the 64
+        // The lane's row/column bases are made opaque once per tile: otherwise hipcc hoists the
         // per-element row ids / addresses out of the tile loop and spills them around the k-loop.
         int rbase = wm0 + 4 * lh, cbase = wn0 + li;
         asm volatile("" : "+v"(rbase), "+v"(cbase));
         const long long rows_left = a.M - m0;
         const int lim = (rows_left > BM ? BM : (int)rows_left) - rbase;  // element row offset c is valid iff c < lim
-#define TSC_FOR_ACC(BODY)                                                                     \
-    _Pragma("unroll") for (int bm = 0; bm < 2; ++bm) _Pragma("unroll") for (int bn = 0; bn < 2; ++bn) \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
-        const int c = bm * 32 + (r & 3) + 8 * (r >> 2);                                       \
-        const float v = acc[bm][bn][r];                                                       \
-        BODY                                                                                  \
+#define TSC_FOR_ACC(BODY)                                                                       \
+    _Pragma("unroll") for (int bm = 0; bm < WMB; ++bm) _Pragma("unroll") for (int bn = 0; bn < WNB; ++bn) \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                        \
+        const int c = bm * 32 + (r & 3) + 8 * (r >> 2);                                         \
+        const float v = acc[bm][bn][r];                                                         \
+        BODY                                                                                    \
     }
 
 #pragma unroll
-        for (int bm = 0; bm < 2; ++bm)
+        for (int bm = 0; bm < WMB; ++bm)
 #pragma unroll
-            for (int bn = 0; bn < 2; ++bn)
+            for (int bn = 0; bn < WNB; ++bn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[bm][bn][r] += be[bn];
 
+#ifdef TSC_ABL_NOEPI
+        if (acc[0][0][0] == 12345.678f)
+#endif
         if (MODE == TSC_MODE_DENSE) {
             float *obase = a.out + (m0 + rbase) * a.N + (n0 + cbase);
             TSC_FOR_ACC({
@@ -287,14 +355,14 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
             // in HBM.  A lane whose push finds the queue full keeps its place and the round is
             // repeated, so nothing is dropped whatever the data.  Cost: one barrier per tile when
             // nobody has a candidate, two when somebody has.
-            float thr[2];
+            float thr[WNB];
             int any = 0;
 #pragma unroll
-            for (int bn = 0; bn < 2; ++bn) {
+            for (int bn = 0; bn < WNB; ++bn) {
                 thr[bn] = nok[bn] ? sm.thr[cbase + bn * 32] : __builtin_inff();
                 float mx = acc[0][bn][0];
 #pragma unroll
-                for (int bm = 0; bm < 2; ++bm)
+                for (int bm = 0; bm < WMB; ++bm)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[bm][bn][r]);
                 any |= (mx > 0.f && mx >= thr[bn]) ? 1 : 0;
@@ -383,23 +451,64 @@ __global__ __launch_bounds__(NT, 2) void encode_f32_kernel(const EncodeArgs a) {
     }
 }
 
-template <int MODE>
-int launch(const EncodeArgs &a, hipStream_t stream) {
+// Geometry choice: TSC_F32_TILE=128|256 overrides the default (an A/B switch for measurements).
+bool use_large_tile() {
+    static const int choice = [] {
+        const char *e = getenv("TSC_F32_TILE");
+        if (e && atoi(e) == 128) return 0;
+        if (e && atoi(e) == 256) return 1;
+        return TSC_F32_DEFAULT_LARGE;
+    }();
+    return choice != 0;
+}
+
+// number of token-tile groups per column tile such that the grid is a whole number of waves of
+// resident workgroups (every workgroup does the same amount of work, so a ragged last wave of
+// workgroups is pure idle time)
+int balanced_split(int n_tiles_n, long long n_tiles_m, int resident, int cap) {
+    if (cap > n_tiles_m) cap = (int)(n_tiles_m < 1 ? 1 : n_tiles_m);
+    for (int s = 1; s <= cap; ++s)
+        if (((long long)n_tiles_n * s) % resident == 0) return s;
+    int s = (2 * resident + n_tiles_n - 1) / n_tiles_n;
+    if (s < 1) s = 1;
+    return s > cap ? cap : s;
+}
+
+template <class C, int MODE>
+int launch(EncodeArgs a, hipStream_t stream) {
+    a.n_tiles_n = (a.N + C::BN - 1) / C::BN;
+    if (a.m_split <= 0)
+        a.m_split = balanced_split(a.n_tiles_n, (a.M + C::BM - 1) / C::BM, 256 * C::OCC, 64);
     const long long grid = (long long)a.n_tiles_n * a.m_split;
     if (grid <= 0 || grid > 0x7fffffffLL) return tsc_fail(TSC_ERR_ARG, "encode grid %lld out of range", grid);
-    hipLaunchKernelGGL(encode_f32_kernel<MODE>, dim3((unsigned)grid), dim3(NT), 0, stream, a);
+    if (a.K % BK == 0)
+        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true>), dim3((unsigned)grid), dim3(NT), 0, stream, a);
+    else
+        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, false>), dim3((unsigned)grid), dim3(NT), 0, stream, a);
     TSC_HIP_CHECK(hipGetLastError());
     return TSC_OK;
 }
 
-}  // namespace
-
-int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream) {
-    if (a.M <= 0) return TSC_OK;
+template <class C>
+int dispatch(int mode, const EncodeArgs &a, hipStream_t stream) {
     switch (mode) {
-        case TSC_MODE_DENSE: return launch<TSC_MODE_DENSE>(a, stream);
-        case TSC_MODE_TOPK: return launch<TSC_MODE_TOPK>(a, stream);
-        case TSC_MODE_SPARSE: return launch<TSC_MODE_SPARSE>(a, stream);
+        case TSC_MODE_DENSE: return launch<C, TSC_MODE_DENSE>(a, stream);
+        case TSC_MODE_TOPK: return launch<C, TSC_MODE_TOPK>(a, stream);
+        case TSC_MODE_SPARSE: return launch<C, TSC_MODE_SPARSE>(a, stream);
     }
     return tsc_fail(TSC_ERR_ARG, "unknown encode mode %d", mode);
+}
+
+}  // namespace
+
+// a.m_split <= 0 asks for the balanced split; a.n_tiles_n is filled in here
+int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream) {
+    if (a.M <= 0) return TSC_OK;
+    return use_large_tile() ? dispatch<CfgLarge>(mode, a, stream) : dispatch<CfgSmall>(mode, a, stream);
+}
+
+int tsc_encode_f32_recommended_slots(int d_sae) {
+    if (use_large_tile())
+        return balanced_split((d_sae + CfgLarge::BN - 1) / CfgLarge::BN, 1 << 30, 256 * CfgLarge::OCC, 16);
+    return balanced_split((d_sae + CfgSmall::BN - 1) / CfgSmall::BN, 1 << 30, 256 * CfgSmall::OCC, 16);
 }

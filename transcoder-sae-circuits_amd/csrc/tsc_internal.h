@@ -40,7 +40,8 @@ struct EncodeArgs {
     int *sp_count;       // [M], zeroed by the caller
     int max_active;
 };
-int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream);
+int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream);  // a.m_split <= 0: balanced
+int tsc_encode_f32_recommended_slots(int d_sae);
 int tsc_launch_encode_bf16(int mode, const EncodeArgs &a, const void *W_bf16, hipStream_t stream);
 int tsc_pack_w_bf16(const float *W, int K, int N, void *dst, hipStream_t stream);
 

@@ -12,7 +12,8 @@ from typing import Optional, Tuple
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtsc_hip.so")
+# TSC_HIP_LIBRARY selects another build of the same library (kernel A/B experiments); never a fallback
+_LIB_PATH = os.environ.get("TSC_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtsc_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
 F32, BF16 = 0, 1
