@@ -46,11 +46,20 @@ const char *tsc_last_error(void);
  * out_bias [d_out] (= b_dec_out for a transcoder, = b_dec for a z-SAE; mlp_transcoder.py:131-147,
  * z_sae.py:62).  W_dec/out_bias may be NULL if only encode entry points are used.
  * compute_dtype TSC_BF16 makes one device-side bf16 copy of W_enc (hipMalloc, freed by destroy).
+ * Every handle also owns bias' = b_enc - b_dec @ W_enc ([d_sae] fp32, summed in fp64): the encode
+ * kernels contract the raw x and add bias', which equals the reference's
+ * (x - b_dec) @ W_enc + b_enc (mlp_transcoder.py:200-212) up to fp32 rounding -- the same folding
+ * the reference itself uses in get_feature_scores (autointerpretability.py:228-233).
  * Requires d_in % 4 == 0 and d_sae % 4 == 0, 16-byte aligned pointers.
+ *
+ * tsc_dict_refresh recomputes what the handle derived from the weights (bias', the bf16 copy);
+ * call it after the borrowed tensors were updated in place (an optimiser step on the reference's
+ * nn.Parameters keeps the pointers but changes the values).
  */
 int tsc_dict_create(tsc_dict_t **out, int d_in, int d_sae, int d_out, int compute_dtype,
                     const float *W_enc, const float *b_enc, const float *b_dec,
                     const float *W_dec, const float *out_bias, tsc_stream_t stream);
+int tsc_dict_refresh(tsc_dict_t *dict, tsc_stream_t stream);
 int tsc_dict_destroy(tsc_dict_t *dict);
 
 /*

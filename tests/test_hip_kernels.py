@@ -145,6 +145,48 @@ def test_fused_topk_exact_ties_prefer_smaller_token_id():
     assert bool((idx.cpu()[~live] == -1).all())
 
 
+def _rank_own_dense(acts, k, base=0):
+    """Top-k per feature of a dense activation matrix under the reference's ranking (value
+    descending, token id ascending, positives only): the expected lists when the values are the
+    GPU's own, so the comparison is bit-exact and isolates the list logic from sgemm rounding."""
+    a = acts.cpu().numpy()
+    m, f = a.shape
+    vals = np.zeros((f, k), np.float32)
+    idx = np.full((f, k), -1, np.int64)
+    ids = np.arange(m)
+    for j in range(f):
+        col = a[:, j]
+        order = np.lexsort((ids, -col))[:k]
+        order = order[col[order] > 0]
+        vals[j, :len(order)] = col[order]
+        idx[j, :len(order)] = order + base
+    return torch.from_numpy(vals), torch.from_numpy(idx)
+
+
+@pytest.mark.parametrize("k,n_slots,batch", [(20, 8, 1024), (20, 1, 700), (7, 3, 333), (33, 2, 4096)])
+def test_fused_topk_bit_exact_on_duplicated_tokens(k, n_slots, batch):
+    """Real token streams repeat contexts (every sequence starts with the same BOS activation), so
+    exact value ties are common: blocks of tokens are repeated here, in the middle of the stream
+    too, and the lists must equal the ranking of the GPU's own dense activations bit for bit
+    (k = 33 takes the kernel variant whose lists are not mirrored in LDS)."""
+    import tsc_hip
+
+    g, w, xs, n_seq, n_pos = gi.g2_inputs()
+    gen = torch.Generator().manual_seed(11)
+    a, b, c = xs[:900], xs[900:1500], xs[1500:2300]
+    x = torch.cat([a, b, a[:500], c, b, a[200:700], c[:50].repeat(6, 1)])
+    x = x[torch.randperm(x.shape[0], generator=gen)].contiguous()
+    d, _ = _dd(w)
+    xg = x.to(DEV)
+    exp_v, exp_i = _rank_own_dense(d.encode_dense(xg), k, base=50)
+    st = tsc_hip.TopkState(1536, k, DEV, n_slots=n_slots)
+    for s in range(0, xg.shape[0], batch):
+        d.encode_topk(xg[s:s + batch], 50 + s, st)
+    vals, idx = st.finalize()
+    assert torch.equal(vals.cpu(), exp_v)
+    assert torch.equal(idx.cpu(), exp_i)
+
+
 def test_topk_merge_and_resume():
     import tsc_hip
 

@@ -17,6 +17,7 @@ ap.add_argument("--launches", type=int, default=12)
 ap.add_argument("--mode", default="topk", choices=["topk", "dense", "sparse"])
 ap.add_argument("--slots", type=int, default=0)
 ap.add_argument("--bf16", action="store_true")
+ap.add_argument("--b-enc", type=float, default=None, help="override b_enc (e.g. -100: nothing is ever active)")
 args = ap.parse_args()
 
 import tsc_hip  # noqa: E402
@@ -24,6 +25,8 @@ from bench import make_device_dictionary  # noqa: E402
 
 dev = torch.device("cuda", 0)
 W, be, bd = make_device_dictionary(args.d_sae, 1, dev)
+if args.b_enc is not None:
+    be.fill_(args.b_enc)
 d = tsc_hip.DeviceDict(W, be, bd, compute_dtype=tsc_hip.BF16 if args.bf16 else tsc_hip.F32)
 st = tsc_hip.TopkState(args.d_sae, 20, dev, n_slots=args.slots or None)
 g = torch.Generator(device=dev).manual_seed(3)
@@ -46,13 +49,11 @@ ms = e0.elapsed_time(e1) / n
 print(f"{args.mode} d_sae={args.d_sae} tokens={args.tokens}: {ms:.3f} ms/launch, "
       f"{2.0 * 768 * args.d_sae * args.tokens / ms / 1e9:.1f} TFLOP/s")
 lib = tsc_hip.lib()
-if hasattr(lib, "tsc_debug_read_stamps"):
+if hasattr(lib, "tsc_debug_read_stamps"):  # diagnosis builds (-DTSC_STAMPS) only
     import ctypes
     buf = (ctypes.c_ulonglong * 16)()
-    lib.tsc_debug_read_stamps(buf)
-    names = ["loop top", "gload issue", "frag1+mfma16 (kk0)", "frag2+mfma16 (kk1)", "frag3+mfma16 (kk2)", "sstore",
-             "mfma8 (kk3a)", "barrier", "frag0'+mfma8 (kk3b)", "epilogue"]
-    tot = sum(buf[i] for i in range(10))
-    print("stamps of block 0 / wave 0 over its lifetime in the LAST launch (cycles, share):")
-    for i, n in enumerate(names):
-        print(f"  {n:24s} {buf[i]:12d}  {100.0 * buf[i] / max(tot, 1):5.1f}%")
+    lib.tsc_debug_read_stamps(buf, 0)
+    names = ["k-loop", "pre-check", "push scan", "barrier 1", "owner", "barrier 2", "-", "-"]
+    for w, o in (("wave 0", 0), ("wave 3", 8)):
+        tot = sum(buf[o + i] for i in range(8))
+        print(w, " ".join(f"{n}={100.0 * buf[o + i] / max(tot, 1):.2f}%" for i, n in enumerate(names) if n != "-"))

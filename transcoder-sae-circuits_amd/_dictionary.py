@@ -43,7 +43,7 @@ class HipDictionaryMixin:
     def device_dict(self, bf16: bool = False) -> tsc_hip.DeviceDict:
         """The library handle for the current parameter storage (fp32, or the bf16-MFMA variant)."""
         self._require_gpu_fp32()
-        tensors = (self.W_enc.data, self.b_enc.data, self.b_dec.data, self.W_dec.data, self._out_bias().data)
+        tensors = (self.W_enc.detach(), self.b_enc.detach(), self.b_dec.detach(), self.W_dec.detach(), self._out_bias().detach())
         tensors = tuple(t if t.is_contiguous() else t.contiguous() for t in tensors)
         attr = "_hip_bf16" if bf16 else "_hip"
         cur = getattr(self, attr)
@@ -52,6 +52,8 @@ class HipDictionaryMixin:
                 cur.close()
             cur = tsc_hip.DeviceDict(*tensors, compute_dtype=tsc_hip.BF16 if bf16 else tsc_hip.F32)
             object.__setattr__(self, attr, cur)
+        else:
+            cur.refresh_if_modified()
         return cur
 
     # ---- capabilities beyond the reference API (the fused hot path) ----

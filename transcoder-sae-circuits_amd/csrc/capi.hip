@@ -32,7 +32,7 @@ int check_dict_x(const tsc_dict_t *d, const float *x, int64_t M) {
 EncodeArgs base_args(const tsc_dict_t *d, const float *x, int64_t M) {
     EncodeArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = x; a.W = d->W_enc; a.b_enc = d->b_enc; a.b_dec = d->b_dec;
+    a.x = x; a.W = d->W_enc; a.b_enc = d->b_enc; a.b_dec = d->b_dec; a.bias = d->bias_fold;
     a.M = M; a.K = d->d_in; a.N = d->d_sae;
     a.m_split = 0;  // the launcher picks the tile geometry and the balanced split
     return a;
@@ -79,10 +79,13 @@ int tsc_dict_create(tsc_dict_t **out, int d_in, int d_sae, int d_out, int comput
             delete d;
             return tsc_fail(TSC_ERR_HIP, "hipMalloc of the bf16 W_enc copy failed: %s", hipGetErrorString(e));
         }
-        int rc = tsc_pack_w_bf16(W_enc, d_in, d_sae, d->W_enc_bf16, (hipStream_t)stream);
+    }
+    {
+        hipError_t e = hipMalloc((void **)&d->bias_fold, (size_t)d_sae * sizeof(float));
+        int rc = e == hipSuccess ? tsc_dict_refresh(d, stream)
+                                 : tsc_fail(TSC_ERR_HIP, "hipMalloc of the folded bias failed: %s", hipGetErrorString(e));
         if (rc != TSC_OK) {
-            (void)hipFree(d->W_enc_bf16);
-            delete d;
+            tsc_dict_destroy(d);
             return rc;
         }
     }
@@ -90,9 +93,20 @@ int tsc_dict_create(tsc_dict_t **out, int d_in, int d_sae, int d_out, int comput
     return TSC_OK;
 }
 
+int tsc_dict_refresh(tsc_dict_t *d, tsc_stream_t stream) {
+    if (!d) return tsc_fail(TSC_ERR_ARG, "null dictionary handle");
+    hipStream_t s = (hipStream_t)stream;
+    if (d->W_enc_bf16) {
+        int rc = tsc_pack_w_bf16(d->W_enc, d->d_in, d->d_sae, d->W_enc_bf16, s);
+        if (rc != TSC_OK) return rc;
+    }
+    return tsc_launch_fold_bias(d->W_enc, d->b_enc, d->b_dec, d->d_in, d->d_sae, d->bias_fold, s);
+}
+
 int tsc_dict_destroy(tsc_dict_t *d) {
     if (!d) return TSC_OK;
     if (d->W_enc_bf16) (void)hipFree(d->W_enc_bf16);
+    if (d->bias_fold) (void)hipFree(d->bias_fold);
     delete d;
     return TSC_OK;
 }

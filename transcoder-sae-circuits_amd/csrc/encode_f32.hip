@@ -32,7 +32,8 @@ namespace {
 
 constexpr int BK = 32, NT = 256;
 constexpr int LDA = BK + 4;  // 144-byte rows: ds_read_b128 of 16 consecutive rows hits 16 distinct slots
-constexpr int QCAP = 512;
+constexpr int QD = 4;   // candidate slots per feature and round
+constexpr int KL = 20;  // list length up to which the lists' values are mirrored in LDS
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -45,26 +46,29 @@ struct Cfg {
     static constexpr int B_TPR = BN / 4;                      // threads per W row
     static constexpr int B_RPP = NT / B_TPR;                  // W rows per pass
     static constexpr int B_LD = BK / B_RPP;                   // float4 loads of W per thread and k-step
+    static constexpr bool LDS_LISTS = BN * KL * 4 <= 12 * 1024;  // the mirror must leave room for the staging buffers
     static_assert(BN <= 256, "one owner thread per feature, column index packed in 8 bits");
     static_assert(BM <= 256, "row index packed in 8 bits");
 };
 typedef Cfg<2, 2, 2> CfgSmall;
 typedef Cfg<4, 4, 1> CfgLarge;
 
-template <class C>
+template <class C, bool DMA, bool LLDS>
 struct __attribute__((aligned(16))) Smem {
-    float A[2][C::BM * LDA];
+    float A[2][C::BM * (DMA ? BK : LDA)];  // register staging: padded rows; LDS-DMA: 32-float rows, 16-byte chunks XOR-swizzled
     float B[2][BK * C::BN];  // [k][n] image, read one dword per lane (32 consecutive n: conflict-free)
+    float lv[LLDS ? C::BN * KL : 4];  // TOPK, k <= KL: the values of the workgroup's lists, [feature][KL]
     float thr[C::BN];
-    float q_val[QCAP];
-    int q_loc[QCAP];  // (row in tile << 8) | column in tile
+    float q_val[C::BN * QD];         // candidates of one round, [feature][QD]
+    unsigned char q_row[C::BN * QD];  // their rows in the tile
+    int f_nq[C::BN];                  // candidates pushed for the feature this round (may exceed QD)
     // per-feature list state, owned by thread t < BN: entries held, and the lowest-ranked entry
     long long f_worst_id[C::BN];
     float f_worst_v[C::BN];
-    int f_worst_pos[C::BN];
-    int f_cnt[C::BN];
-    int q_count;
-    int pad[3];
+    unsigned char f_worst_pos[C::BN];  // k <= 64
+    unsigned char f_cnt[C::BN];
+    int pushed, again;  // round flags: somebody pushed / somebody found its feature's slots full
+    int pad[2];
 };
 
 __device__ __forceinline__ bool ranks_below(float v, long long id, float w, long long wid) {
@@ -72,17 +76,35 @@ __device__ __forceinline__ bool ranks_below(float v, long long id, float w, long
     return v < w || (v == w && id > wid);
 }
 
+#ifdef TSC_STAMPS  // diagnosis builds only: cycles per phase, summed over the workgroups' waves 0 and 3
+__device__ unsigned long long g_stamps[16];
+#define TSC_STAMP(i) { const unsigned long long t_ = clock64(); st_acc[i] += t_ - st_last; st_last = t_; }
+#else
+#define TSC_STAMP(i)
+#endif
+
 #ifdef TSC_NO_PIN
 #define TSC_PIN
 #else
 #define TSC_PIN __builtin_amdgcn_sched_barrier(0);
 #endif
 
-template <class C, int MODE, bool KALIGNED>
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// KALIGNED: K % 32 == 0 (no k tail).  DMA (needs KALIGNED and a.bias = b_enc - b_dec @ W_enc):
+// tiles go global -> LDS by global_load_lds_dwordx4, no register staging.
+// LLDS (TOPK with DMA, k <= KL): the values of the lists live in LDS for the whole launch (HBM is written
+// through), so folding a candidate into its list needs no load from HBM.
+template <class C, int MODE, bool KALIGNED, bool DMA, bool LLDS>
 __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs a) {
     constexpr int WMB = C::WMB, WNB = C::WNB, BM = C::BM, BN = C::BN;
-    __shared__ Smem<C> sm;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int LDA_ = DMA ? BK : LDA;
+    constexpr int APW = BM / 32, BPW = BN / 32;  // 1-KiB DMA pieces per wave and k-step (x tile, W tile)
+    static_assert(!DMA || KALIGNED, "DMA staging has no k tail handling");
+    static_assert(!LLDS || (DMA && MODE == TSC_MODE_TOPK), "LDS lists belong to the fused top-k DMA kernel");
+    __shared__ Smem<C, DMA, LLDS> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int wm0 = (wave >> 1) * (WMB * 32), wn0 = (wave & 1) * (WNB * 32);
 
@@ -104,6 +126,9 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
     const int n0 = nt * BN;
     const long long n_mtiles = (a.M + BM - 1) / BM;
     const int nk = (a.K + BK - 1) / BK;
+#ifdef TSC_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = clock64();
+#endif
 
     // epilogue constants of this lane: WNB features (column li of each 32-wide block)
     float be[WNB];
@@ -112,7 +137,7 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
     for (int bn = 0; bn < WNB; ++bn) {
         const int n = n0 + wn0 + bn * 32 + li;
         nok[bn] = n < a.N;
-        be[bn] = nok[bn] ? a.b_enc[n] : 0.f;
+        be[bn] = nok[bn] ? (DMA ? a.bias[n] : a.b_enc[n]) : 0.f;
     }
 
     // TOPK: thread t < BN owns feature n0 + t of list set `slot`; its view of the list (kept in
@@ -140,6 +165,7 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
                                 wv = ev[j]; wid = eid[j]; wpos = i0 + j;
                             }
                             cnt = i0 + j + 1;
+                            if constexpr (LLDS) sm.lv[tid * KL + i0 + j] = ev[j];
                         }
                 }
             }
@@ -149,11 +175,12 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
             sm.f_worst_id[tid] = wid;
             sm.thr[tid] = cnt == a.topk ? wv : 0.f;
         }
-        if (tid == 0) sm.q_count = 0;
+        if (tid < BN) sm.f_nq[tid] = 0;
+        if (tid == 0) sm.pushed = sm.again = 0;
         __syncthreads();
     }
 
-    f32x4 ra[C::A_LD], rb[C::B_LD], rbd;
+    f32x4 ra[DMA ? 1 : C::A_LD], rb[DMA ? 1 : C::B_LD], rbd;
     const int a_row = tid >> 3, a_col = (tid & 7) * 4;
     const int b_row = tid / C::B_TPR, b_col = (tid % C::B_TPR) * 4;
 
@@ -164,20 +191,53 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
     // Addresses are a wave-uniform 64-bit base (advanced by scalar adds per k-step) plus a 32-bit
     // lane offset that is constant per token tile: vector-side address arithmetic per k-step costs
     // matrix throughput directly.
-    const int nc = n0 + b_col < a.N - 4 ? n0 + b_col : a.N - 4;
-    unsigned a_voff[C::A_LD], b_voff[C::B_LD];
+    //
+    // DMA staging: one global_load_lds_dwordx4 writes 64 lanes x 16 B = 1 KiB of LDS linearly, from
+    // per-lane source addresses.  x piece p = rows 8p..8p+7 of the tile, 128 B (32 k) per row; the
+    // 16-byte chunk c of row r is stored at chunk c ^ ((r >> 1) & 7), which makes the A-fragment
+    // ds_read_b128 of 16 consecutive rows conflict-free without padding; the swizzle is applied to
+    // the source address.  W piece q = floats 256q..256q+255 of the [32][BN] image, unswizzled.
+    unsigned a_voff[DMA ? APW : C::A_LD], b_voff[DMA ? BPW : C::B_LD];
     const unsigned bd_voff = (unsigned)a_col * 4u;
+    if constexpr (DMA) {
 #pragma unroll
-    for (int i = 0; i < C::B_LD; ++i)
-        b_voff[i] = ((unsigned)(b_row + C::B_RPP * i) * (unsigned)a.N + (unsigned)nc) * 4u;
+        for (int j = 0; j < BPW; ++j) {
+            const int f = (wave * BPW + j) * 256 + lane * 4;
+            const int col = n0 + f % BN;
+            b_voff[j] = ((unsigned)(f / BN) * (unsigned)a.N + (unsigned)(col < a.N - 4 ? col : a.N - 4)) * 4u;
+        }
+    } else {
+        const int nc = n0 + b_col < a.N - 4 ? n0 + b_col : a.N - 4;
+#pragma unroll
+        for (int i = 0; i < C::B_LD; ++i)
+            b_voff[i] = ((unsigned)(b_row + C::B_RPP * i) * (unsigned)a.N + (unsigned)nc) * 4u;
+    }
     auto set_tile = [&](long long m0) {  // lane offsets of the x rows of the tile being prefetched
         const long long rows_left = a.M - m0;  // >= 1
         const int rmax = rows_left > BM ? BM - 1 : (int)rows_left - 1;
+        if constexpr (DMA) {
 #pragma unroll
-        for (int i = 0; i < C::A_LD; ++i) {
-            const int r = a_row + 32 * i < rmax ? a_row + 32 * i : rmax;
-            a_voff[i] = (unsigned)(r * a.K + a_col) * 4u;
+            for (int j = 0; j < APW; ++j) {
+                const int row = (wave * APW + j) * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((row >> 1) & 7);
+                a_voff[j] = (unsigned)((row < rmax ? row : rmax) * a.K + c * 4) * 4u;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < C::A_LD; ++i) {
+                const int r = a_row + 32 * i < rmax ? a_row + 32 * i : rmax;
+                a_voff[i] = (unsigned)(r * a.K + a_col) * 4u;
+            }
         }
+    };
+    // DMA piece j of this wave (j < APW: x, else W) of the k-step at (xt, wt) into LDS buffer `buf`
+    auto dma_piece = [&](int j, const char *xt, const char *wt, int buf) {
+        if (j < APW)
+            __builtin_amdgcn_global_load_lds((gptr_t)(xt + a_voff[j]), (lptr_t)&sm.A[buf][(wave * APW + j) * 256],
+                                             16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(wt + b_voff[j - APW]),
+                                             (lptr_t)&sm.B[buf][(wave * BPW + j - APW) * 256], 16, 0, 0);
     };
     auto gload = [&](long long m0, int k0) {
         if (KALIGNED) {
@@ -189,6 +249,7 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
 #pragma unroll
             for (int i = 0; i < C::B_LD; ++i) rb[i] = *(const f32x4 *)(wt + b_voff[i]);
         } else {
+            const int nc = n0 + b_col < a.N - 4 ? n0 + b_col : a.N - 4;
             const int kc = k0 + a_col < a.K - 4 ? k0 + a_col : a.K - 4;
             rbd = *(const f32x4 *)(a.b_dec + kc);
             const char *xt = (const char *)(a.x + m0 * a.K);
@@ -226,7 +287,8 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
         const float *Bs = sm.B[buf];
 #pragma unroll
         for (int bm = 0; bm < WMB; ++bm)
-            f.af[bm] = *(const f32x4 *)&As[(wm0 + bm * 32 + li) * LDA + kk * 8 + lh * 4];
+            f.af[bm] = *(const f32x4 *)&As[(wm0 + bm * 32 + li) * LDA_ +
+                                           (DMA ? (((kk * 2 + lh) ^ ((li >> 1) & 7)) * 4) : kk * 8 + lh * 4)];
 #pragma unroll
         for (int bn = 0; bn < WNB; ++bn)
 #pragma unroll
@@ -241,8 +303,15 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
     long long mt = slot;
     if (mt < n_mtiles) {
         set_tile(mt * BM);
-        gload(mt * BM, 0);
-        sstore(0, 0);
+        if constexpr (DMA) {
+            const char *xt = (const char *)(a.x + mt * BM * a.K);
+#pragma unroll
+            for (int j = 0; j < APW + BPW; ++j) dma_piece(j, xt, (const char *)a.W, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            gload(mt * BM, 0);
+            sstore(0, 0);
+        }
     }
     __syncthreads();
     Frag F, G;
@@ -258,10 +327,16 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[bm][bn][r] = 0.f;
 
-#define TSC_MFMA(FR, S0, S1)                                                                     \
-    _Pragma("unroll") for (int s = S0; s < S1; ++s) _Pragma("unroll") for (int bm = 0; bm < WMB; ++bm) \
-        _Pragma("unroll") for (int bn = 0; bn < WNB; ++bn) acc[bm][bn] =                         \
-            __builtin_amdgcn_mfma_f32_32x32x2f32(FR.af[bm][s], FR.bf[bn][s], acc[bm][bn], 0, 0, 0);
+#define TSC_MFMA_S(FR, s)                                                                        \
+    _Pragma("unroll") for (int bm = 0; bm < WMB; ++bm) _Pragma("unroll") for (int bn = 0; bn < WNB; ++bn) \
+        acc[bm][bn] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR.af[bm][s], FR.bf[bn][s], acc[bm][bn], 0, 0, 0);
+#define TSC_MFMA(FR, S0, S1) _Pragma("unroll") for (int s = S0; s < S1; ++s) { TSC_MFMA_S(FR, s) }
+#ifdef TSC_ABL_NOFRAG  // timing experiments only: results are garbage
+#define TSC_LDFRAG(b, k, f) { _Pragma("unroll") for (int q_ = 0; q_ < WMB; ++q_) asm volatile("" : "+v"(f.af[q_])); \
+                              _Pragma("unroll") for (int q_ = 0; q_ < WNB; ++q_) asm volatile("" : "+v"(f.bf[q_])); }
+#else
+#define TSC_LDFRAG(b, k, f) ldfrag(b, k, f);
+#endif
 
         for (int kt = 0; kt < nk; ++kt) {
             // what to prefetch: the next k-step of this tile, or the first of the next tile
@@ -269,39 +344,80 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
             const long long next_m0 = last_k ? (mt + a.m_split) * BM : m0;
             const int next_k0 = last_k ? 0 : (kt + 1) * BK;
             const bool more = !last_k || mt + a.m_split < n_mtiles;
-#ifndef TSC_ABL_NOGLOAD
-            if (last_k && more) set_tile(next_m0);
-            if (more) gload(next_m0, next_k0);
-#endif
             // The order below is pinned with sched_barrier(0): left alone, hipcc sinks every fragment
             // read to just before its first use and hoists the barrier above the MFMAs meant to cover it.
-#ifdef TSC_ABL_NOFRAG  // timing experiments only: results are garbage
-#define TSC_LDFRAG(b, k, f) { _Pragma("unroll") for (int q_ = 0; q_ < WMB; ++q_) asm volatile("" : "+v"(f.af[q_])); \
-                              _Pragma("unroll") for (int q_ = 0; q_ < WNB; ++q_) asm volatile("" : "+v"(f.bf[q_])); }
-#else
-#define TSC_LDFRAG(b, k, f) ldfrag(b, k, f);
+            if constexpr (DMA) {
+                // The other buffer is free since the last barrier.  Its pieces are issued one per
+                // MFMA k-step over the first two groups (an issue burst would leave the matrix pipe
+                // idle) and have the last two groups to land; __syncthreads() waits for them
+                // (vmcnt(0)) before the barrier.
+                constexpr int PPS = (APW + BPW) / 8;
+                const char *xt = (const char *)(a.x + next_m0 * a.K + next_k0);
+                const char *wt = (const char *)(a.W + (long long)next_k0 * a.N);
+#ifndef TSC_ABL_NOGLOAD
+                if (last_k && more) set_tile(next_m0);
 #endif
-            TSC_PIN TSC_LDFRAG(parity, 1, G)
-            TSC_PIN TSC_MFMA(F, 0, 4)
-            TSC_PIN TSC_LDFRAG(parity, 2, F)
-            TSC_PIN TSC_MFMA(G, 0, 4)
-            TSC_PIN TSC_LDFRAG(parity, 3, G)
-            TSC_PIN TSC_MFMA(F, 0, 4)
-            // stage the prefetched k-step into the other buffer (free since the last barrier),
-            // cover the LDS write latency and the barrier with the first half of the last group,
-            // and the first fragment read of the new buffer with the second half
-#ifndef TSC_ABL_NOSSTORE
-            TSC_PIN if (more) sstore(parity ^ 1, next_k0);
+                TSC_PIN TSC_LDFRAG(parity, 1, G)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#ifndef TSC_ABL_NOGLOAD
+                    TSC_PIN if (more) {
+#pragma unroll
+                        for (int jj = 0; jj < PPS; ++jj) dma_piece(s * PPS + jj, xt, wt, parity ^ 1);
+                    }
 #endif
-            TSC_PIN TSC_MFMA(G, 0, 2)
+                    TSC_PIN TSC_MFMA_S(F, s)
+                }
+                TSC_PIN TSC_LDFRAG(parity, 2, F)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#ifndef TSC_ABL_NOGLOAD
+                    TSC_PIN if (more) {
+#pragma unroll
+                        for (int jj = 0; jj < PPS; ++jj) dma_piece((4 + s) * PPS + jj, xt, wt, parity ^ 1);
+                    }
+#endif
+                    TSC_PIN TSC_MFMA_S(G, s)
+                }
+                TSC_PIN TSC_LDFRAG(parity, 3, G)
+                TSC_PIN TSC_MFMA(F, 0, 4)
+                TSC_PIN TSC_MFMA(G, 0, 2)
 #ifndef TSC_ABL_NOBARRIER
-            TSC_PIN __syncthreads();
+                TSC_PIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
 #endif
-            TSC_PIN if (more) { TSC_LDFRAG(parity ^ 1, 0, F) }
-            TSC_PIN TSC_MFMA(G, 2, 4)
-            TSC_PIN
+                TSC_PIN if (more) { TSC_LDFRAG(parity ^ 1, 0, F) }
+                TSC_PIN TSC_MFMA(G, 2, 4)
+                TSC_PIN
+            } else {
+#ifndef TSC_ABL_NOGLOAD
+                if (last_k && more) set_tile(next_m0);
+                if (more) gload(next_m0, next_k0);
+#endif
+                TSC_PIN TSC_LDFRAG(parity, 1, G)
+                TSC_PIN TSC_MFMA(F, 0, 4)
+                TSC_PIN TSC_LDFRAG(parity, 2, F)
+                TSC_PIN TSC_MFMA(G, 0, 4)
+                TSC_PIN TSC_LDFRAG(parity, 3, G)
+                TSC_PIN TSC_MFMA(F, 0, 4)
+                // stage the prefetched k-step into the other buffer (free since the last barrier),
+                // cover the LDS write latency and the barrier with the first half of the last group,
+                // and the first fragment read of the new buffer with the second half
+#ifndef TSC_ABL_NOSSTORE
+                TSC_PIN if (more) sstore(parity ^ 1, next_k0);
+#endif
+                TSC_PIN TSC_MFMA(G, 0, 2)
+#ifndef TSC_ABL_NOBARRIER
+                TSC_PIN __syncthreads();
+#endif
+                TSC_PIN if (more) { TSC_LDFRAG(parity ^ 1, 0, F) }
+                TSC_PIN TSC_MFMA(G, 2, 4)
+                TSC_PIN
+            }
             parity ^= 1;
         }
+#undef TSC_MFMA_S
+#undef TSC_LDFRAG
 #undef TSC_MFMA
 
         // ---------------------------------------------------------------- epilogues
@@ -348,50 +464,67 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
                 }
             })
         } else {
-            // Lane-local pre-check: the lane's largest value per feature against that feature's
-            // k-th best (rows past M are copies of the last real row, so they cannot raise an alarm
-            // that the exact check below would not dismiss).  Lanes with a candidate push it on a
-            // bounded LDS queue; the thread that owns the feature folds it into the feature's list
-            // in HBM.  A lane whose push finds the queue full keeps its place and the round is
-            // repeated, so nothing is dropped whatever the data.  Cost: one barrier per tile when
-            // nobody has a candidate, two when somebody has.
+            // Lane-local pre-check per 32x32 block: the lane's largest value of the block against
+            // its feature's k-th best (rows past M are copies of the last real row, so they cannot
+            // raise an alarm that the exact check below would not dismiss).  Lanes with a candidate
+            // push it into one of the QD slots of its feature; the thread that owns the feature
+            // folds its slots into the feature's list.  A lane that finds the slots full keeps its
+            // place and the round is repeated, so nothing is dropped whatever the data.  Cost: one
+            // barrier per tile when nobody has a candidate, two when somebody has.
+            TSC_STAMP(0)
             float thr[WNB];
-            int any = 0;
 #pragma unroll
-            for (int bn = 0; bn < WNB; ++bn) {
-                thr[bn] = nok[bn] ? sm.thr[cbase + bn * 32] : __builtin_inff();
-                float mx = acc[0][bn][0];
+            for (int bn = 0; bn < WNB; ++bn) thr[bn] = nok[bn] ? sm.thr[cbase + bn * 32] : __builtin_inff();
+            unsigned hot = 0;  // bit bm * WNB + bn: the block holds a candidate of this lane
 #pragma unroll
-                for (int bm = 0; bm < WMB; ++bm)
+            for (int bm = 0; bm < WMB; ++bm)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[bm][bn][r]);
-                any |= (mx > 0.f && mx >= thr[bn]) ? 1 : 0;
-            }
+                for (int bn = 0; bn < WNB; ++bn) {
+                    float mx = acc[bm][bn][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[bm][bn][r]);
+                    hot |= (mx > 0.f && mx >= thr[bn]) ? 1u << (bm * WNB + bn) : 0u;
+                }
             int consumed = 0;
-            for (;;) {  // sm.q_count == 0 on entry
-                if (any) {
+            TSC_STAMP(1)
+            for (;;) {  // sm.pushed == sm.again == 0 and sm.f_nq[] == 0 on entry
+                if (hot) {
                     int ord = 0, blocked = 0;
-                    TSC_FOR_ACC({
-                        if (v > 0.f && v >= thr[bn] && c < lim) {
-                            if (ord >= consumed && !blocked) {
-                                const int pos = atomicAdd(&sm.q_count, 1);
-                                if (pos < QCAP) {
-                                    sm.q_val[pos] = v;
-                                    sm.q_loc[pos] = ((rbase + c) << 8) | (cbase + bn * 32);
-                                    ++consumed;
-                                } else {
-                                    blocked = 1;
+#pragma unroll
+                    for (int bm = 0; bm < WMB; ++bm)
+#pragma unroll
+                        for (int bn = 0; bn < WNB; ++bn)
+                            if (hot & (1u << (bm * WNB + bn))) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int c = bm * 32 + (r & 3) + 8 * (r >> 2);
+                                    const float v = acc[bm][bn][r];
+                                    if (v > 0.f && v >= thr[bn] && c < lim) {
+                                        if (ord >= consumed && !blocked) {
+                                            const int col = cbase + bn * 32;
+                                            const int pos = atomicAdd(&sm.f_nq[col], 1);
+                                            if (pos < QD) {
+                                                sm.q_val[col * QD + pos] = v;
+                                                sm.q_row[col * QD + pos] = (unsigned char)(rbase + c);
+                                                sm.pushed = 1;
+                                                ++consumed;
+                                            } else {
+                                                sm.again = 1;
+                                                blocked = 1;
+                                            }
+                                        }
+                                        ++ord;
+                                    }
                                 }
                             }
-                            ++ord;
-                        }
-                    })
                 }
+                TSC_STAMP(2)
                 __syncthreads();
-                const int pushed = sm.q_count;  // > QCAP: some lane is blocked and needs another round
-                if (pushed == 0) break;
-                if (tid < BN && n0 + tid < a.N) {
-                    const int nq = pushed < QCAP ? pushed : QCAP;
+                TSC_STAMP(3)
+                if (!sm.pushed) break;
+                const int again = sm.again;
+                const int nq = tid < BN ? (sm.f_nq[tid] < QD ? sm.f_nq[tid] : QD) : 0;
+                if (nq > 0) {  // features past N never receive candidates (thr = inf)
                     const int k = a.topk;
                     const long long off = ((long long)slot * a.N + n0 + tid) * k;
                     float *lv = a.tk_vals + off;
@@ -400,17 +533,50 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
                     float wv = sm.f_worst_v[tid];
                     long long wid = sm.f_worst_id[tid];
                     for (int e = 0; e < nq; ++e) {
-                        const int loc = sm.q_loc[e];
-                        if ((loc & 255) != tid) continue;
-                        const float v = sm.q_val[e];
-                        const long long id = a.token_base + m0 + (loc >> 8);
+                        const float v = sm.q_val[tid * QD + e];
+                        const long long id = a.token_base + m0 + sm.q_row[tid * QD + e];
                         if (cnt < k) {
                             lv[cnt] = v;
                             lid[cnt] = id;
+                            if constexpr (LLDS) sm.lv[tid * KL + cnt] = v;
                             if (cnt == 0 || ranks_below(v, id, wv, wid)) {
                                 wv = v; wid = id; wpos = cnt;
                             }
                             ++cnt;
+                            continue;
+                        }
+                        if constexpr (LLDS) {
+                            // wid < 0: the id of the lowest-ranked entry has not been needed yet
+                            if (v < wv) continue;
+                            if (v == wv) {
+                                if (wid < 0) wid = lid[wpos];
+                                if (id > wid) continue;
+                            }
+                            const int p = wpos;
+                            lv[p] = v;
+                            lid[p] = id;
+                            sm.lv[tid * KL + p] = v;
+                            // the new lowest value, from LDS; among equal values the largest id ranks
+                            // lowest, which takes the ids from HBM -- only when there is such a tie
+                            float mv = v;
+                            int mp = p, ties = 1;
+                            for (int i = 0; i < k; ++i) {
+                                const float x = sm.lv[tid * KL + i];
+                                if (i == p) continue;
+                                if (x < mv) { mv = x; mp = i; ties = 1; }
+                                else if (x == mv) ++ties;
+                            }
+                            wv = mv; wpos = mp;
+                            wid = mp == p ? id : -1;
+                            if (ties > 1) {
+                                long long best = -1;
+                                for (int i = 0; i < k; ++i)
+                                    if (sm.lv[tid * KL + i] == mv) {
+                                        const long long t = i == p ? id : lid[i];
+                                        if (t > best) { best = t; wpos = i; }
+                                    }
+                                wid = best;
+                            }
                         } else if (ranks_below(wv, wid, v, id)) {
                             const int p = wpos;
                             lv[p] = v;
@@ -441,14 +607,37 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
                     sm.f_worst_id[tid] = wid;
                     sm.thr[tid] = cnt == k ? wv : 0.f;
                 }
-                __syncthreads();  // lists and thresholds updated; everyone has read q_count
-                if (tid == 0) sm.q_count = 0;
-                if (pushed <= QCAP) break;  // reset is ordered before the next tile's pushes by the k-loop barriers
+                if (tid < BN) sm.f_nq[tid] = 0;
+                TSC_STAMP(4)
+                __syncthreads();  // lists and thresholds updated; everyone has read the round flags
+                TSC_STAMP(5)
+                if (tid == 0) sm.pushed = sm.again = 0;
+                if (!again) break;  // the resets are ordered before the next tile's pushes by the k-loop barriers
+                // thr[] is deliberately not refreshed: `consumed` counts this lane's candidates in
+                // the order of one fixed threshold; the owner's exact check dismisses stale ones
                 __syncthreads();
             }
         }
 #undef TSC_FOR_ACC
     }
+#ifdef TSC_STAMPS
+    if (MODE == TSC_MODE_TOPK && (tid == 0 || tid == 192)) {
+        const int o = tid == 0 ? 0 : 8;
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[o + i], st_acc[i]);
+    }
+#endif
+}
+
+// bias[n] = b_enc[n] - sum_k b_dec[k] * W[k,n], summed in fp64 and rounded once: lets the DMA kernel
+// contract the raw x (relu((x - b_dec) @ W + b_enc) == relu(x @ W + bias) up to fp32 rounding).
+__global__ __launch_bounds__(256) void fold_bias_kernel(const float *__restrict__ W, const float *__restrict__ b_enc,
+                                                        const float *__restrict__ b_dec, int K, int N,
+                                                        float *__restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    double s = 0.0;
+    for (int k = 0; k < K; ++k) s += (double)b_dec[k] * (double)W[(size_t)k * N + n];
+    out[n] = (float)((double)b_enc[n] - s);
 }
 
 // Geometry choice: TSC_F32_TILE=128|256 overrides the default (an A/B switch for measurements).
@@ -460,6 +649,23 @@ bool use_large_tile() {
         return TSC_F32_DEFAULT_LARGE;
     }();
     return choice != 0;
+}
+
+// TSC_F32_STAGING=reg forces register staging (A/B switch; the k-tail kernel always uses it)
+bool use_dma() {
+    static const bool on = [] {
+        const char *e = getenv("TSC_F32_STAGING");
+        return !(e && e[0] == 'r');
+    }();
+    return on;
+}
+
+bool use_lds_lists() {  // TSC_F32_LISTS=hbm: A/B switch
+    static const bool on = [] {
+        const char *e = getenv("TSC_F32_LISTS");
+        return !(e && e[0] == 'h');
+    }();
+    return on;
 }
 
 // number of token-tile groups per column tile such that the grid is a whole number of waves of
@@ -481,10 +687,16 @@ int launch(EncodeArgs a, hipStream_t stream) {
         a.m_split = balanced_split(a.n_tiles_n, (a.M + C::BM - 1) / C::BM, 256 * C::OCC, 64);
     const long long grid = (long long)a.n_tiles_n * a.m_split;
     if (grid <= 0 || grid > 0x7fffffffLL) return tsc_fail(TSC_ERR_ARG, "encode grid %lld out of range", grid);
-    if (a.K % BK == 0)
-        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true>), dim3((unsigned)grid), dim3(NT), 0, stream, a);
+    const bool dma = a.K % BK == 0 && a.bias && use_dma();
+    if (dma && MODE == TSC_MODE_TOPK && C::LDS_LISTS && a.topk <= KL && use_lds_lists())
+        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, MODE == TSC_MODE_TOPK && C::LDS_LISTS>), dim3((unsigned)grid),
+                           dim3(NT), 0, stream, a);
+    else if (dma)
+        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, false>), dim3((unsigned)grid), dim3(NT), 0, stream, a);
+    else if (a.K % BK == 0)
+        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, false, false>), dim3((unsigned)grid), dim3(NT), 0, stream, a);
     else
-        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, false>), dim3((unsigned)grid), dim3(NT), 0, stream, a);
+        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, false, false, false>), dim3((unsigned)grid), dim3(NT), 0, stream, a);
     TSC_HIP_CHECK(hipGetLastError());
     return TSC_OK;
 }
@@ -500,6 +712,24 @@ int dispatch(int mode, const EncodeArgs &a, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef TSC_STAMPS
+extern "C" int tsc_debug_read_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+int tsc_launch_fold_bias(const float *W, const float *b_enc, const float *b_dec, int K, int N, float *out,
+                         hipStream_t stream) {
+    hipLaunchKernelGGL(fold_bias_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, W, b_enc, b_dec, K, N, out);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
 
 // a.m_split <= 0 asks for the balanced split; a.n_tiles_n is filled in here
 int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream) {

@@ -27,6 +27,7 @@ _SIGNATURES = {
     "tsc_last_error": (_c.c_char_p, []),
     "tsc_dict_create": (_c.c_int, [_c.POINTER(_c.c_void_p), _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                    _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "tsc_dict_refresh": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "tsc_dict_destroy": (_c.c_int, [_c.c_void_p]),
     "tsc_encode_dense": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p]),
     "tsc_topk_recommended_slots": (_c.c_int, [_c.c_int]),
@@ -122,8 +123,24 @@ class DeviceDict:
                                          compute_dtype, W_enc.data_ptr(), b_enc.data_ptr(), b_dec.data_ptr(),
                                          ptr_dec, ptr_bias, _stream()))
 
+        self._versions = self._param_versions()
+
+    def _param_versions(self):
+        return tuple(t._version for t in self._keep[:3])
+
     def same_storage(self, *tensors) -> bool:
         return all(a.data_ptr() == b.data_ptr() for a, b in zip(self._keep, tensors))
+
+    def refresh(self) -> None:
+        """Recompute what the handle derived from the weight values (``tsc_dict_refresh``)."""
+        with torch.cuda.device(self.device):
+            _check(lib().tsc_dict_refresh(self._handle, _stream()))
+        self._versions = self._param_versions()
+
+    def refresh_if_modified(self) -> None:
+        """In-place updates of W_enc / b_enc / b_dec bump torch's version counters."""
+        if self._param_versions() != self._versions:
+            self.refresh()
 
     def close(self) -> None:
         if self._handle:
