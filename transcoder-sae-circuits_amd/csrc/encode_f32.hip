@@ -25,6 +25,7 @@
 // VALU shares the SIMD's issue with the fp32 MFMA and a wave issues in order, so what decides the
 // rate is the number of non-MFMA instructions per MFMA; the large tile halves it.
 #include <cstdlib>
+#include <type_traits>
 
 #include "tsc_internal.h"
 
@@ -92,7 +93,7 @@ __device__ unsigned long long g_stamps[16];
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-// KALIGNED: K % 32 == 0 (no k tail).  DMA (needs KALIGNED and a.bias = b_enc - b_dec @ W_enc):
+// KALIGNED: K % 32 == 0 (no k tail).  DMA (needs K % 64 == 0 and a.bias = b_enc - b_dec @ W_enc):
 // tiles go global -> LDS by global_load_lds_dwordx4, no register staging.
 // LLDS (TOPK with DMA, k <= KL): the values of the lists live in LDS for the whole launch (HBM is written
 // through), so folding a candidate into its list needs no load from HBM.
@@ -230,14 +231,18 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
             }
         }
     };
-    // DMA piece j of this wave (j < APW: x, else W) of the k-step at (xt, wt) into LDS buffer `buf`
-    auto dma_piece = [&](int j, const char *xt, const char *wt, int buf) {
+    // DMA piece j of this wave (j < APW: x, else W) of the k-step at (xt, wt) into LDS buffer `buf`.
+    // lds_a / lds_b: LDS byte addresses of this wave's first x / W piece in buffer 0.
+    const unsigned lds_a0 = (unsigned)(size_t)(lptr_t)&sm.A[0][wave * APW * 256];
+    const unsigned lds_b0 = (unsigned)(size_t)(lptr_t)&sm.B[0][wave * BPW * 256];
+    auto dma_piece = [&](int j, const char *xt, const char *wt, int buf, unsigned lds_a, unsigned lds_b) {
         if (j < APW)
-            __builtin_amdgcn_global_load_lds((gptr_t)(xt + a_voff[j]), (lptr_t)&sm.A[buf][(wave * APW + j) * 256],
-                                             16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(xt + a_voff[j]),
+                                             (lptr_t)(size_t)(lds_a + buf * (unsigned)sizeof(sm.A[0]) + j * 1024), 16, 0, 0);
         else
             __builtin_amdgcn_global_load_lds((gptr_t)(wt + b_voff[j - APW]),
-                                             (lptr_t)&sm.B[buf][(wave * BPW + j - APW) * 256], 16, 0, 0);
+                                             (lptr_t)(size_t)(lds_b + buf * (unsigned)sizeof(sm.B[0]) + (j - APW) * 1024),
+                                             16, 0, 0);
     };
     auto gload = [&](long long m0, int k0) {
         if (KALIGNED) {
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
         if constexpr (DMA) {
             const char *xt = (const char *)(a.x + mt * BM * a.K);
 #pragma unroll
-            for (int j = 0; j < APW + BPW; ++j) dma_piece(j, xt, (const char *)a.W, 0);
+            for (int j = 0; j < APW + BPW; ++j) dma_piece(j, xt, (const char *)a.W, 0, lds_a0, lds_b0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             gload(mt * BM, 0);
@@ -331,93 +336,105 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
     _Pragma("unroll") for (int bm = 0; bm < WMB; ++bm) _Pragma("unroll") for (int bn = 0; bn < WNB; ++bn) \
         acc[bm][bn] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR.af[bm][s], FR.bf[bn][s], acc[bm][bn], 0, 0, 0);
 #define TSC_MFMA(FR, S0, S1) _Pragma("unroll") for (int s = S0; s < S1; ++s) { TSC_MFMA_S(FR, s) }
-#ifdef TSC_ABL_NOFRAG  // timing experiments only: results are garbage
-#define TSC_LDFRAG(b, k, f) { _Pragma("unroll") for (int q_ = 0; q_ < WMB; ++q_) asm volatile("" : "+v"(f.af[q_])); \
-                              _Pragma("unroll") for (int q_ = 0; q_ < WNB; ++q_) asm volatile("" : "+v"(f.bf[q_])); }
-#else
-#define TSC_LDFRAG(b, k, f) ldfrag(b, k, f);
-#endif
 
-        for (int kt = 0; kt < nk; ++kt) {
-            // what to prefetch: the next k-step of this tile, or the first of the next tile
-            const bool last_k = kt + 1 == nk;
-            const long long next_m0 = last_k ? (mt + a.m_split) * BM : m0;
-            const int next_k0 = last_k ? 0 : (kt + 1) * BK;
-            const bool more = !last_k || mt + a.m_split < n_mtiles;
-            // The order below is pinned with sched_barrier(0): left alone, hipcc sinks every fragment
-            // read to just before its first use and hoists the barrier above the MFMAs meant to cover it.
-            if constexpr (DMA) {
-                // The other buffer is free since the last barrier.  Its pieces are issued one per
-                // MFMA k-step over the first two groups (an issue burst would leave the matrix pipe
-                // idle) and have the last two groups to land; __syncthreads() waits for them
-                // (vmcnt(0)) before the barrier.
-                constexpr int PPS = (APW + BPW) / 8;
-                const char *xt = (const char *)(a.x + next_m0 * a.K + next_k0);
-                const char *wt = (const char *)(a.W + (long long)next_k0 * a.N);
-#ifndef TSC_ABL_NOGLOAD
-                if (last_k && more) set_tile(next_m0);
-#endif
-                TSC_PIN TSC_LDFRAG(parity, 1, G)
+        // The order inside a k-step is pinned with sched_barrier(0): left alone, hipcc sinks every
+        // fragment read to just before its first use and hoists the barrier above the MFMAs meant
+        // to cover it.
+        if constexpr (DMA) {
+            // Every instruction a wave issues costs the matrix pipe about as much as it would cost
+            // the VALU, so the k-loop is unrolled by two (nk is even: K % 64 == 0): the LDS buffer
+            // is then a compile-time constant, every LDS address an immediate offset, and there is
+            // no per-step branch.  A k-step computes from buffer PAR and fills buffer PAR ^ 1 with
+            // the next k-step -- or, in the tile's last step, with the first k-step of the
+            // workgroup's next tile (of this tile again if there is none: nobody reads that).  The
+            // pieces are issued one per MFMA k-step over the first two groups (an issue burst
+            // would leave the matrix pipe idle) and have the last two groups to land.
+            constexpr int PPS = (APW + BPW) / 8;
+            const bool has_next = mt + a.m_split < n_mtiles;
+            const long long next_m0 = has_next ? (mt + a.m_split) * BM : m0;
+            const size_t w_step = (size_t)BK * a.N * 4;
+            const char *xt = (const char *)(a.x + m0 * a.K) + BK * 4;  // k-step 1 of this tile
+            const char *wt = (const char *)a.W + w_step;
+            auto kstep = [&](auto par_) {
+                constexpr int PAR = decltype(par_)::value;
+                // keep the tile bases in scalar registers (saddr + 32-bit lane offset addressing);
+                // otherwise loop strength reduction turns every piece's address into a 64-bit
+                // vector induction variable
+                const char *xp = xt, *wp = wt;
+                // likewise the piece destinations: one base plus an immediate each, not 16 hoisted constants
+                unsigned la = lds_a0, lb = lds_b0;
+                asm volatile("" : "+s"(xp), "+s"(wp), "+s"(la), "+s"(lb));
+#pragma unroll
+                for (int j = 0; j < BPW; ++j) asm volatile("" : "+v"(b_voff[j]));  // same, for the hoisted zero-extensions
+#pragma unroll
+                for (int j = 0; j < APW; ++j) asm volatile("" : "+v"(a_voff[j]));
+                TSC_PIN ldfrag(PAR, 1, G);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-#ifndef TSC_ABL_NOGLOAD
-                    TSC_PIN if (more) {
+                    TSC_PIN
 #pragma unroll
-                        for (int jj = 0; jj < PPS; ++jj) dma_piece(s * PPS + jj, xt, wt, parity ^ 1);
-                    }
-#endif
+                    for (int jj = 0; jj < PPS; ++jj) dma_piece(s * PPS + jj, xp, wp, PAR ^ 1, la, lb);
                     TSC_PIN TSC_MFMA_S(F, s)
                 }
-                TSC_PIN TSC_LDFRAG(parity, 2, F)
+                TSC_PIN ldfrag(PAR, 2, F);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-#ifndef TSC_ABL_NOGLOAD
-                    TSC_PIN if (more) {
+                    TSC_PIN
 #pragma unroll
-                        for (int jj = 0; jj < PPS; ++jj) dma_piece((4 + s) * PPS + jj, xt, wt, parity ^ 1);
-                    }
-#endif
+                    for (int jj = 0; jj < PPS; ++jj) dma_piece((4 + s) * PPS + jj, xp, wp, PAR ^ 1, la, lb);
                     TSC_PIN TSC_MFMA_S(G, s)
                 }
-                TSC_PIN TSC_LDFRAG(parity, 3, G)
+                TSC_PIN ldfrag(PAR, 3, G);
                 TSC_PIN TSC_MFMA(F, 0, 4)
                 TSC_PIN TSC_MFMA(G, 0, 2)
-#ifndef TSC_ABL_NOBARRIER
-                TSC_PIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                TSC_PIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed
                 __syncthreads();
-#endif
-                TSC_PIN if (more) { TSC_LDFRAG(parity ^ 1, 0, F) }
+                TSC_PIN ldfrag(PAR ^ 1, 0, F);
                 TSC_PIN TSC_MFMA(G, 2, 4)
                 TSC_PIN
-            } else {
-#ifndef TSC_ABL_NOGLOAD
+            };
+            for (int kt = 0; kt < nk; kt += 2) {
+                kstep(std::integral_constant<int, 0>());
+                if (kt + 2 == nk) {
+                    set_tile(next_m0);
+                    xt = (const char *)(a.x + next_m0 * a.K);
+                    wt = (const char *)a.W;
+                } else {
+                    xt += BK * 4;
+                    wt += w_step;
+                }
+                kstep(std::integral_constant<int, 1>());
+                xt += BK * 4;
+                wt += w_step;
+            }
+        } else {
+            for (int kt = 0; kt < nk; ++kt) {
+                // what to prefetch: the next k-step of this tile, or the first of the next tile
+                const bool last_k = kt + 1 == nk;
+                const long long next_m0 = last_k ? (mt + a.m_split) * BM : m0;
+                const int next_k0 = last_k ? 0 : (kt + 1) * BK;
+                const bool more = !last_k || mt + a.m_split < n_mtiles;
                 if (last_k && more) set_tile(next_m0);
                 if (more) gload(next_m0, next_k0);
-#endif
-                TSC_PIN TSC_LDFRAG(parity, 1, G)
+                TSC_PIN ldfrag(parity, 1, G);
                 TSC_PIN TSC_MFMA(F, 0, 4)
-                TSC_PIN TSC_LDFRAG(parity, 2, F)
+                TSC_PIN ldfrag(parity, 2, F);
                 TSC_PIN TSC_MFMA(G, 0, 4)
-                TSC_PIN TSC_LDFRAG(parity, 3, G)
+                TSC_PIN ldfrag(parity, 3, G);
                 TSC_PIN TSC_MFMA(F, 0, 4)
                 // stage the prefetched k-step into the other buffer (free since the last barrier),
                 // cover the LDS write latency and the barrier with the first half of the last group,
                 // and the first fragment read of the new buffer with the second half
-#ifndef TSC_ABL_NOSSTORE
                 TSC_PIN if (more) sstore(parity ^ 1, next_k0);
-#endif
                 TSC_PIN TSC_MFMA(G, 0, 2)
-#ifndef TSC_ABL_NOBARRIER
                 TSC_PIN __syncthreads();
-#endif
-                TSC_PIN if (more) { TSC_LDFRAG(parity ^ 1, 0, F) }
+                TSC_PIN if (more) ldfrag(parity ^ 1, 0, F);
                 TSC_PIN TSC_MFMA(G, 2, 4)
                 TSC_PIN
+                parity ^= 1;
             }
-            parity ^= 1;
         }
 #undef TSC_MFMA_S
-#undef TSC_LDFRAG
 #undef TSC_MFMA
 
         // ---------------------------------------------------------------- epilogues
@@ -443,9 +460,6 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[bm][bn][r] += be[bn];
 
-#ifdef TSC_ABL_NOEPI
-        if (acc[0][0][0] == 12345.678f)
-#endif
         if (MODE == TSC_MODE_DENSE) {
             float *obase = a.out + (m0 + rbase) * a.N + (n0 + cbase);
             TSC_FOR_ACC({
@@ -687,7 +701,7 @@ int launch(EncodeArgs a, hipStream_t stream) {
         a.m_split = balanced_split(a.n_tiles_n, (a.M + C::BM - 1) / C::BM, 256 * C::OCC, 64);
     const long long grid = (long long)a.n_tiles_n * a.m_split;
     if (grid <= 0 || grid > 0x7fffffffLL) return tsc_fail(TSC_ERR_ARG, "encode grid %lld out of range", grid);
-    const bool dma = a.K % BK == 0 && a.bias && use_dma();
+    const bool dma = a.K % (2 * BK) == 0 && a.bias && use_dma();
     if (dma && MODE == TSC_MODE_TOPK && C::LDS_LISTS && a.topk <= KL && use_lds_lists())
         hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, MODE == TSC_MODE_TOPK && C::LDS_LISTS>), dim3((unsigned)grid),
                            dim3(NT), 0, stream, a);

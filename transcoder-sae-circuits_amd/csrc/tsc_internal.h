@@ -27,7 +27,7 @@ int tsc_fail(int code, const char *fmt, ...);
 enum { TSC_MODE_DENSE = 0, TSC_MODE_TOPK = 1, TSC_MODE_SPARSE = 2 };
 struct EncodeArgs {
     const float *x, *W, *b_enc, *b_dec;
-    const float *bias;   // b_enc - b_dec @ W_enc, or null: selects the LDS-DMA kernel when K % 32 == 0
+    const float *bias;   // b_enc - b_dec @ W_enc, or null: selects the LDS-DMA kernel when K % 64 == 0
     long long M;
     int K, N;
     int n_tiles_n, m_split;
