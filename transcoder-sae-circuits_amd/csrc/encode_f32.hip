@@ -84,6 +84,14 @@ __device__ unsigned long long g_stamps[16];
 #define TSC_STAMP(i)
 #endif
 
+// cache-policy bits of the LDS-DMA loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef TSC_X_AUX
+#define TSC_X_AUX 0
+#endif
+#ifndef TSC_W_AUX
+#define TSC_W_AUX 0
+#endif
+
 #ifdef TSC_NO_PIN
 #define TSC_PIN
 #else
@@ -238,11 +246,11 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
     auto dma_piece = [&](int j, const char *xt, const char *wt, int buf, unsigned lds_a, unsigned lds_b) {
         if (j < APW)
             __builtin_amdgcn_global_load_lds((gptr_t)(xt + a_voff[j]),
-                                             (lptr_t)(size_t)(lds_a + buf * (unsigned)sizeof(sm.A[0]) + j * 1024), 16, 0, 0);
+                                             (lptr_t)(size_t)(lds_a + buf * (unsigned)sizeof(sm.A[0]) + j * 1024), 16, 0, TSC_X_AUX);
         else
             __builtin_amdgcn_global_load_lds((gptr_t)(wt + b_voff[j - APW]),
                                              (lptr_t)(size_t)(lds_b + buf * (unsigned)sizeof(sm.B[0]) + (j - APW) * 1024),
-                                             16, 0, 0);
+                                             16, 0, TSC_W_AUX);
     };
     auto gload = [&](long long m0, int k0) {
         if (KALIGNED) {
