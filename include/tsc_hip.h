@@ -45,7 +45,10 @@ const char *tsc_last_error(void);
  * outlive the handle: W_enc [d_in,d_sae], b_enc [d_sae], b_dec [d_in], W_dec [d_sae,d_out],
  * out_bias [d_out] (= b_dec_out for a transcoder, = b_dec for a z-SAE; mlp_transcoder.py:131-147,
  * z_sae.py:62).  W_dec/out_bias may be NULL if only encode entry points are used.
- * compute_dtype TSC_BF16 makes one device-side bf16 copy of W_enc (hipMalloc, freed by destroy).
+ * compute_dtype TSC_BF16 (needs d_in % 128 == 0) makes one device-side transposed bf16 copy of W_enc and
+ * a 32768-row bf16 staging buffer for x (hipMalloc, freed by destroy); such a handle computes
+ * relu(bf16(x - b_dec) @ bf16(W_enc) + b_enc) with fp32 accumulation, and its calls must not overlap
+ * on different streams (they share the staging buffer).
  * Every handle also owns bias' = b_enc - b_dec @ W_enc ([d_sae] fp32, summed in fp64): the encode
  * kernels contract the raw x and add bias', which equals the reference's
  * (x - b_dec) @ W_enc + b_enc (mlp_transcoder.py:200-212) up to fp32 rounding -- the same folding

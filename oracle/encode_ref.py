@@ -23,6 +23,17 @@ def encode_ref(x: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, b_dec:
     return torch.clamp_min(pre, 0.0)
 
 
+def encode_bf16_ref(x: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, b_dec: torch.Tensor) -> torch.Tensor:
+    """The ``TSC_BF16`` contract (BASELINE config 5; no counterpart in the reference, whose shipped
+    dictionaries are fp32): the same expression as :func:`encode_ref` on bf16-rounded operands
+    (round to nearest even, ``(x - b_dec)`` rounded after the subtraction) with fp32 accumulation.
+    Parity unpinned by reference fixtures -- this function *defines* the mode; it is tied to the
+    reference only through :func:`encode_ref` (the two agree to bf16 precision, tested)."""
+    centred = (x.to(torch.float32) - b_dec).to(torch.bfloat16).to(torch.float32)
+    W = W_enc.to(torch.bfloat16).to(torch.float32)
+    return torch.clamp_min(torch.matmul(centred, W) + b_enc, 0.0)
+
+
 def decode_ref(acts: torch.Tensor, W_dec: torch.Tensor, out_bias: torch.Tensor) -> torch.Tensor:
     """``acts @ W_dec + bias``: mlp_transcoder.py:131-138 (bias = ``b_dec_out``),
     z_sae.py:62 (bias = ``b_dec``)."""

@@ -187,6 +187,72 @@ def test_fused_topk_bit_exact_on_duplicated_tokens(k, n_slots, batch):
     assert torch.equal(idx.cpu(), exp_i)
 
 
+BF16_RTOL = 2.0 ** -7  # relative to the fp32 restatement on bf16-rounded operands
+
+
+def test_bf16_encode_dense_matches_restatement():
+    import tsc_hip
+
+    g, wt, wz, x = gi.g1_inputs()
+    for w in (wt, wz):
+        d, _ = _dd(w, compute_dtype=tsc_hip.BF16)
+        for m in (1, 64, 200):
+            xm = x.repeat(4, 1)[:m].contiguous()
+            ref = E.encode_bf16_ref(xm, w["W_enc"], w["b_enc"], w["b_dec"])
+            out = d.encode_dense(xm.to(DEV)).cpu()
+            # products of bf16 numbers are exact in fp32: only the summation order differs
+            assert torch.allclose(out, ref, rtol=BF16_RTOL, atol=1e-5), float((out - ref).abs().max())
+            assert torch.allclose(out, ref, rtol=1e-4, atol=2e-5), float((out - ref).abs().max())
+        # and the mode stays within bf16 precision of the reference's fp32 encode
+        full = E.encode_ref(x, w["W_enc"], w["b_enc"], w["b_dec"])
+        out = d.encode_dense(x.to(DEV)).cpu()
+        assert float((out - full).abs().max()) <= 0.05 * float(full.abs().max())
+
+
+@pytest.mark.parametrize("k,n_slots,batch", [(20, 4, 1024), (33, 1, 5000)])
+def test_bf16_fused_topk_bit_exact_against_own_dense(k, n_slots, batch):
+    import tsc_hip
+
+    g, w, xs, n_seq, n_pos = gi.g2_inputs()
+    x = torch.cat([xs, xs[:700]])  # with exact ties
+    d, _ = _dd(w, compute_dtype=tsc_hip.BF16)
+    xg = x.to(DEV)
+    exp_v, exp_i = _rank_own_dense(d.encode_dense(xg), k)
+    st = tsc_hip.TopkState(1536, k, DEV, n_slots=n_slots)
+    for s in range(0, xg.shape[0], batch):
+        d.encode_topk(xg[s:s + batch], s, st)
+    vals, idx = st.finalize()
+    assert torch.equal(vals.cpu(), exp_v)
+    assert torch.equal(idx.cpu(), exp_i)
+
+
+def test_bf16_wide_dictionary_config5_shape():
+    """d_sae = 131072 (BASELINE config 5), chunked input (more rows than the bf16 workspace holds)."""
+    import tsc_hip
+    from synthetic_dicts import make_dictionary_weights
+
+    w = make_dictionary_weights(768, 131072, seed=5, b_enc=-0.35)
+    d, _ = _dd(w, compute_dtype=tsc_hip.BF16)
+    m = 32768 + 1000
+    x = torch.randn(m, 768, generator=torch.Generator().manual_seed(2))
+    st = tsc_hip.TopkState(131072, 20, DEV)
+    d.encode_topk(x.to(DEV), 7, st)
+    vals, idx = st.finalize()
+    # oracle on a slice of the features (the full CPU sgemm would take minutes)
+    sl = slice(65536 - 512, 65536 + 512)
+    ws = {"W_enc": w["W_enc"][:, sl].contiguous(), "b_enc": w["b_enc"][sl].contiguous(), "b_dec": w["b_dec"]}
+    acts = E.encode_bf16_ref(x, ws["W_enc"], ws["b_enc"], ws["b_dec"])
+    rv, ri = _rank_own_dense(acts, 20, base=7)
+    v, i = vals.cpu()[sl], idx.cpu()[sl]
+    assert torch.allclose(v, rv, rtol=BF16_RTOL, atol=1e-5)
+    same = i == ri
+    if not bool(same.all()):  # near-ties may swap; the GPU's token must have (almost) the rank's value
+        for f, j in zip(*torch.nonzero(~same, as_tuple=True)):
+            tok = int(i[f, j]) - 7
+            assert tok >= 0 and abs(float(acts[tok, f]) - float(rv[f, j])) <= 1e-4 * abs(float(rv[f, j])) + 2e-5
+        assert int((~same).sum()) <= same.numel() // 200
+
+
 def test_topk_merge_and_resume():
     import tsc_hip
 

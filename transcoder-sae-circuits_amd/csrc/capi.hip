@@ -39,7 +39,7 @@ EncodeArgs base_args(const tsc_dict_t *d, const float *x, int64_t M) {
 }
 
 int run_encode(const tsc_dict_t *d, int mode, const EncodeArgs &a, hipStream_t s) {
-    if (d->compute_dtype == TSC_BF16) return tsc_launch_encode_bf16(mode, a, d->W_enc_bf16, s);
+    if (d->compute_dtype == TSC_BF16) return tsc_launch_encode_bf16(mode, a, d->W_enc_bf16, d->x_bf16, s);
     return tsc_launch_encode_f32(mode, a, s);
 }
 
@@ -70,14 +70,15 @@ int tsc_dict_create(tsc_dict_t **out, int d_in, int d_sae, int d_out, int comput
     d->d_in = d_in; d->d_sae = d_sae; d->d_out = d_out; d->compute_dtype = compute_dtype;
     d->W_enc = W_enc; d->b_enc = b_enc; d->b_dec = b_dec; d->W_dec = W_dec; d->out_bias = out_bias;
     if (compute_dtype == TSC_BF16) {
-        if ((d_in & 31) || (d_sae & 127)) {
+        if (d_in & 127) {
             delete d;
-            return tsc_fail(TSC_ERR_UNSUPPORTED, "bf16 path needs d_in %% 32 == 0 and d_sae %% 128 == 0");
+            return tsc_fail(TSC_ERR_UNSUPPORTED, "bf16 path needs d_in %% 128 == 0 (got %d)", d_in);
         }
         hipError_t e = hipMalloc(&d->W_enc_bf16, (size_t)d_in * d_sae * 2);
+        if (e == hipSuccess) e = hipMalloc(&d->x_bf16, tsc_bf16_workspace_bytes(d_in));
         if (e != hipSuccess) {
-            delete d;
-            return tsc_fail(TSC_ERR_HIP, "hipMalloc of the bf16 W_enc copy failed: %s", hipGetErrorString(e));
+            tsc_dict_destroy(d);
+            return tsc_fail(TSC_ERR_HIP, "hipMalloc of the bf16 operand buffers failed: %s", hipGetErrorString(e));
         }
     }
     {
@@ -106,6 +107,7 @@ int tsc_dict_refresh(tsc_dict_t *d, tsc_stream_t stream) {
 int tsc_dict_destroy(tsc_dict_t *d) {
     if (!d) return TSC_OK;
     if (d->W_enc_bf16) (void)hipFree(d->W_enc_bf16);
+    if (d->x_bf16) (void)hipFree(d->x_bf16);
     if (d->bias_fold) (void)hipFree(d->bias_fold);
     delete d;
     return TSC_OK;

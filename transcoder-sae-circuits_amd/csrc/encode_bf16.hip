@@ -1,10 +1,91 @@
-// bf16 encode path (v_mfma_f32_32x32x16_bf16): placeholder until the kernel lands; the C-ABI
-// reports TSC_ERR_UNSUPPORTED for TSC_BF16 dictionaries instead of silently computing in fp32.
+// bf16 encode path (TSC_BF16 dictionaries; BASELINE config 5, the wide-dictionary stress case).
+//
+//   acts = relu( bf16(x - b_dec) @ bf16(W_enc) + b_enc ),  products exact, fp32 accumulation
+//
+// The contraction itself is encode_f32_kernel<..., BF16 = true> (encode_f32.hip): same tiling, LDS-DMA
+// staging and epilogues as the fp32 path, with v_mfma_f32_32x32x16_bf16.  This file prepares its operands:
+//   * W_enc once per handle (and on tsc_dict_refresh): rounded to bf16 (nearest even, like torch's
+//     .bfloat16()) and transposed to [d_sae][d_in], so that a feature's k run is contiguous and the W tile is
+//     staged by the same 8-rows-by-128-bytes DMA pieces as the x tile;
+//   * x per call: (x - b_dec) rounded to bf16 into a handle-owned workspace of TSC_BF16_WS_ROWS rows; longer
+//     inputs are processed in chunks of that many rows (stream order makes the reuse safe; calls on one bf16
+//     handle must therefore not overlap on different streams).
 #include "tsc_internal.h"
 
-int tsc_pack_w_bf16(const float *, int, int, void *, hipStream_t) {
-    return tsc_fail(TSC_ERR_UNSUPPORTED, "the bf16 encode path is not built into this library");
+namespace {
+
+constexpr long long TSC_BF16_WS_ROWS = 32768;
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
 }
-int tsc_launch_encode_bf16(int, const EncodeArgs &, const void *, hipStream_t) {
-    return tsc_fail(TSC_ERR_UNSUPPORTED, "the bf16 encode path is not built into this library");
+
+// out[n][k0..k0+7] = bf16(W[k0..k0+7][n]); thread = (n, k0/8): reads coalesced over n, 16-byte writes
+__global__ __launch_bounds__(256) void pack_w_kernel(const float *__restrict__ W, int K, int N,
+                                                    unsigned short *__restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int k0 = blockIdx.y * 8;
+    if (n >= N) return;
+    union { unsigned short h[8]; uint4 v; } u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u.h[j] = f32_to_bf16_rne(W[(size_t)(k0 + j) * N + n]);
+    *(uint4 *)(out + (size_t)n * K + k0) = u.v;
+}
+
+// out[m][k] = bf16(x[m][k] - b_dec[k]); 8 elements per thread
+__global__ __launch_bounds__(256) void convert_x_kernel(const float *__restrict__ x, const float *__restrict__ b_dec,
+                                                       long long n8, int K8, unsigned short *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const int k0 = (int)(i % K8) * 8;
+    const float4 a0 = *(const float4 *)(x + i * 8), a1 = *(const float4 *)(x + i * 8 + 4);
+    const float4 b0 = *(const float4 *)(b_dec + k0), b1 = *(const float4 *)(b_dec + k0 + 4);
+    union { unsigned short h[8]; uint4 v; } u;
+    u.h[0] = f32_to_bf16_rne(a0.x - b0.x); u.h[1] = f32_to_bf16_rne(a0.y - b0.y);
+    u.h[2] = f32_to_bf16_rne(a0.z - b0.z); u.h[3] = f32_to_bf16_rne(a0.w - b0.w);
+    u.h[4] = f32_to_bf16_rne(a1.x - b1.x); u.h[5] = f32_to_bf16_rne(a1.y - b1.y);
+    u.h[6] = f32_to_bf16_rne(a1.z - b1.z); u.h[7] = f32_to_bf16_rne(a1.w - b1.w);
+    *(uint4 *)(out + i * 8) = u.v;
+}
+
+}  // namespace
+
+size_t tsc_bf16_workspace_bytes(int K) { return (size_t)TSC_BF16_WS_ROWS * K * 2; }
+
+int tsc_pack_w_bf16(const float *W, int K, int N, void *dst, hipStream_t stream) {
+    if (K % 8) return tsc_fail(TSC_ERR_UNSUPPORTED, "bf16 pack needs d_in %% 8 == 0");
+    hipLaunchKernelGGL(pack_w_kernel, dim3((N + 255) / 256, K / 8), dim3(256), 0, stream, W, K, N,
+                       (unsigned short *)dst);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
+int tsc_launch_encode_bf16(int mode, const EncodeArgs &a, const void *W_bf16, void *x_bf16, hipStream_t stream) {
+    if (!W_bf16 || !x_bf16) return tsc_fail(TSC_ERR_ARG, "bf16 handle without its operand buffers");
+    for (long long r0 = 0; r0 < a.M; r0 += TSC_BF16_WS_ROWS) {
+        const long long rows = a.M - r0 < TSC_BF16_WS_ROWS ? a.M - r0 : TSC_BF16_WS_ROWS;
+        const long long n8 = rows * (a.K / 8);
+        hipLaunchKernelGGL(convert_x_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream,
+                           a.x + r0 * a.K, a.b_dec, n8, a.K / 8, (unsigned short *)x_bf16);
+        TSC_HIP_CHECK(hipGetLastError());
+        EncodeArgs c = a;
+        c.bf16 = 1;
+        c.x = (const float *)x_bf16;
+        c.W = (const float *)W_bf16;
+        c.bias = a.b_enc;  // b_dec is already subtracted
+        c.M = rows;
+        c.token_base = a.token_base + r0;
+        if (a.out) c.out = a.out + r0 * a.N;
+        if (a.sp_count) {
+            c.sp_feat = a.sp_feat + r0 * a.max_active;
+            c.sp_val = a.sp_val + r0 * a.max_active;
+            c.sp_count = a.sp_count + r0;
+        }
+        const int rc = tsc_launch_encode_f32(mode, c, stream);
+        if (rc != TSC_OK) return rc;
+    }
+    return TSC_OK;
 }

@@ -38,6 +38,7 @@ constexpr int KL = 20;  // list length up to which the lists' values are mirrore
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int WMB_, int WNB_, int OCC_>
 struct Cfg {
@@ -105,10 +106,15 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // tiles go global -> LDS by global_load_lds_dwordx4, no register staging.
 // LLDS (TOPK with DMA, k <= KL): the values of the lists live in LDS for the whole launch (HBM is written
 // through), so folding a candidate into its list needs no load from HBM.
-template <class C, int MODE, bool KALIGNED, bool DMA, bool LLDS>
+// BF16 (needs DMA; K % 128 == 0): a.x is bf16(x - b_dec) [M][K] and a.W is bf16(W_enc) transposed [N][K],
+// both prepared by encode_bf16.hip; a k-step is 64 k (the same 128-byte rows), the W tile is staged exactly
+// like the x tile, and one v_mfma_f32_32x32x16_bf16 replaces four fp32 MFMAs.
+template <class C, int MODE, bool KALIGNED, bool DMA, bool LLDS, bool BF16>
 __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs a) {
     constexpr int WMB = C::WMB, WNB = C::WNB, BM = C::BM, BN = C::BN;
     constexpr int LDA_ = DMA ? BK : LDA;
+    constexpr int ES = BF16 ? 2 : 4;  // bytes per staged element; a k-step is 128 bytes of every row
+    static_assert(!BF16 || DMA, "the bf16 operands are staged by LDS-DMA only");
     constexpr int APW = BM / 32, BPW = BN / 32;  // 1-KiB DMA pieces per wave and k-step (x tile, W tile)
     static_assert(!DMA || KALIGNED, "DMA staging has no k tail handling");
     static_assert(!LLDS || (DMA && MODE == TSC_MODE_TOPK), "LDS lists belong to the fused top-k DMA kernel");
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
     }
     const int n0 = nt * BN;
     const long long n_mtiles = (a.M + BM - 1) / BM;
-    const int nk = (a.K + BK - 1) / BK;
+    const int nk = DMA ? a.K / (128 / ES) : (a.K + BK - 1) / BK;
 #ifdef TSC_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = clock64();
 #endif
@@ -211,9 +217,16 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
     if constexpr (DMA) {
 #pragma unroll
         for (int j = 0; j < BPW; ++j) {
-            const int f = (wave * BPW + j) * 256 + lane * 4;
-            const int col = n0 + f % BN;
-            b_voff[j] = ((unsigned)(f / BN) * (unsigned)a.N + (unsigned)(col < a.N - 4 ? col : a.N - 4)) * 4u;
+            if constexpr (BF16) {  // rows are features; same piece shape and swizzle as the x tile
+                const int row = (wave * BPW + j) * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((row >> 1) & 7);
+                const int n = n0 + row < a.N ? n0 + row : a.N - 1;
+                b_voff[j] = (unsigned)n * (unsigned)a.K * 2u + (unsigned)c * 16u;
+            } else {
+                const int f = (wave * BPW + j) * 256 + lane * 4;
+                const int col = n0 + f % BN;
+                b_voff[j] = ((unsigned)(f / BN) * (unsigned)a.N + (unsigned)(col < a.N - 4 ? col : a.N - 4)) * 4u;
+            }
         }
     } else {
         const int nc = n0 + b_col < a.N - 4 ? n0 + b_col : a.N - 4;
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
             for (int j = 0; j < APW; ++j) {
                 const int row = (wave * APW + j) * 8 + (lane >> 3);
                 const int c = (lane & 7) ^ ((row >> 1) & 7);
-                a_voff[j] = (unsigned)((row < rmax ? row : rmax) * a.K + c * 4) * 4u;
+                a_voff[j] = (unsigned)(row < rmax ? row : rmax) * (unsigned)a.K * (unsigned)ES + (unsigned)c * 16u;
             }
         } else {
 #pragma unroll
@@ -303,10 +316,14 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
             f.af[bm] = *(const f32x4 *)&As[(wm0 + bm * 32 + li) * LDA_ +
                                            (DMA ? (((kk * 2 + lh) ^ ((li >> 1) & 7)) * 4) : kk * 8 + lh * 4)];
 #pragma unroll
-        for (int bn = 0; bn < WNB; ++bn)
+        for (int bn = 0; bn < WNB; ++bn) {
+            if constexpr (BF16) {
+                f.bf[bn] = *(const f32x4 *)&Bs[(wn0 + bn * 32 + li) * BK + (((kk * 2 + lh) ^ ((li >> 1) & 7)) * 4)];
+            } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                f.bf[bn][s] = Bs[(kk * 8 + lh * 4 + s) * BN + wn0 + bn * 32 + li];
+                for (int s = 0; s < 4; ++s) f.bf[bn][s] = Bs[(kk * 8 + lh * 4 + s) * BN + wn0 + bn * 32 + li];
+            }
+        }
     };
 
     // The workgroup's work is one continuous stream of k-steps over all its token tiles: the
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
     if (mt < n_mtiles) {
         set_tile(mt * BM);
         if constexpr (DMA) {
-            const char *xt = (const char *)(a.x + mt * BM * a.K);
+            const char *xt = (const char *)a.x + (size_t)mt * BM * a.K * ES;
 #pragma unroll
             for (int j = 0; j < APW + BPW; ++j) dma_piece(j, xt, (const char *)a.W, 0, lds_a0, lds_b0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -344,6 +361,11 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
     _Pragma("unroll") for (int bm = 0; bm < WMB; ++bm) _Pragma("unroll") for (int bn = 0; bn < WNB; ++bn) \
         acc[bm][bn] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR.af[bm][s], FR.bf[bn][s], acc[bm][bn], 0, 0, 0);
 #define TSC_MFMA(FR, S0, S1) _Pragma("unroll") for (int s = S0; s < S1; ++s) { TSC_MFMA_S(FR, s) }
+#define TSC_MFMA_B(FR, bm, bn)                                                                               \
+    acc[bm][bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FR.af[bm]),             \
+                                                          __builtin_bit_cast(bf16x8, FR.bf[bn]), acc[bm][bn], 0, 0, 0);
+#define TSC_MFMA_BALL(FR)                                                                                    \
+    _Pragma("unroll") for (int bm = 0; bm < WMB; ++bm) _Pragma("unroll") for (int bn = 0; bn < WNB; ++bn) { TSC_MFMA_B(FR, bm, bn) }
 
         // The order inside a k-step is pinned with sched_barrier(0): left alone, hipcc sinks every
         // fragment read to just before its first use and hoists the barrier above the MFMAs meant
@@ -360,8 +382,8 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
             constexpr int PPS = (APW + BPW) / 8;
             const bool has_next = mt + a.m_split < n_mtiles;
             const long long next_m0 = has_next ? (mt + a.m_split) * BM : m0;
-            const size_t w_step = (size_t)BK * a.N * 4;
-            const char *xt = (const char *)(a.x + m0 * a.K) + BK * 4;  // k-step 1 of this tile
+            const size_t w_step = BF16 ? 128 : (size_t)BK * a.N * 4;
+            const char *xt = (const char *)a.x + (size_t)m0 * a.K * ES + 128;  // k-step 1 of this tile
             const char *wt = (const char *)a.W + w_step;
             auto kstep = [&](auto par_) {
                 constexpr int PAR = decltype(par_)::value;
@@ -376,43 +398,68 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
                 for (int j = 0; j < BPW; ++j) asm volatile("" : "+v"(b_voff[j]));  // same, for the hoisted zero-extensions
 #pragma unroll
                 for (int j = 0; j < APW; ++j) asm volatile("" : "+v"(a_voff[j]));
-                TSC_PIN ldfrag(PAR, 1, G);
+                if constexpr (BF16) {
+                    // 4 MFMAs (32 cycles each) per 16-k group: the pieces go out two per MFMA in the
+                    // first group and have the other three to land
+                    constexpr int PPM = (APW + BPW) / (WMB * WNB);
+                    TSC_PIN ldfrag(PAR, 1, G);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
+                    for (int bm = 0; bm < WMB; ++bm)
+#pragma unroll
+                        for (int bn = 0; bn < WNB; ++bn) {
+                            TSC_PIN
+#pragma unroll
+                            for (int jj = 0; jj < PPM; ++jj) dma_piece((bm * WNB + bn) * PPM + jj, xp, wp, PAR ^ 1, la, lb);
+                            TSC_PIN TSC_MFMA_B(F, bm, bn)
+                        }
+                    TSC_PIN ldfrag(PAR, 2, F);
+                    TSC_PIN TSC_MFMA_BALL(G)
+                    TSC_PIN ldfrag(PAR, 3, G);
+                    TSC_PIN TSC_MFMA_BALL(F)
+                    TSC_PIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    TSC_PIN ldfrag(PAR ^ 1, 0, F);
+                    TSC_PIN TSC_MFMA_BALL(G)
                     TSC_PIN
-#pragma unroll
-                    for (int jj = 0; jj < PPS; ++jj) dma_piece(s * PPS + jj, xp, wp, PAR ^ 1, la, lb);
-                    TSC_PIN TSC_MFMA_S(F, s)
-                }
-                TSC_PIN ldfrag(PAR, 2, F);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
+                } else {
+                    TSC_PIN ldfrag(PAR, 1, G);
+    #pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        TSC_PIN
+    #pragma unroll
+                        for (int jj = 0; jj < PPS; ++jj) dma_piece(s * PPS + jj, xp, wp, PAR ^ 1, la, lb);
+                        TSC_PIN TSC_MFMA_S(F, s)
+                    }
+                    TSC_PIN ldfrag(PAR, 2, F);
+    #pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        TSC_PIN
+    #pragma unroll
+                        for (int jj = 0; jj < PPS; ++jj) dma_piece((4 + s) * PPS + jj, xp, wp, PAR ^ 1, la, lb);
+                        TSC_PIN TSC_MFMA_S(G, s)
+                    }
+                    TSC_PIN ldfrag(PAR, 3, G);
+                    TSC_PIN TSC_MFMA(F, 0, 4)
+                    TSC_PIN TSC_MFMA(G, 0, 2)
+                    TSC_PIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed
+                    __syncthreads();
+                    TSC_PIN ldfrag(PAR ^ 1, 0, F);
+                    TSC_PIN TSC_MFMA(G, 2, 4)
                     TSC_PIN
-#pragma unroll
-                    for (int jj = 0; jj < PPS; ++jj) dma_piece((4 + s) * PPS + jj, xp, wp, PAR ^ 1, la, lb);
-                    TSC_PIN TSC_MFMA_S(G, s)
                 }
-                TSC_PIN ldfrag(PAR, 3, G);
-                TSC_PIN TSC_MFMA(F, 0, 4)
-                TSC_PIN TSC_MFMA(G, 0, 2)
-                TSC_PIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed
-                __syncthreads();
-                TSC_PIN ldfrag(PAR ^ 1, 0, F);
-                TSC_PIN TSC_MFMA(G, 2, 4)
-                TSC_PIN
             };
             for (int kt = 0; kt < nk; kt += 2) {
                 kstep(std::integral_constant<int, 0>());
                 if (kt + 2 == nk) {
                     set_tile(next_m0);
-                    xt = (const char *)(a.x + next_m0 * a.K);
+                    xt = (const char *)a.x + (size_t)next_m0 * a.K * ES;
                     wt = (const char *)a.W;
                 } else {
-                    xt += BK * 4;
+                    xt += 128;
                     wt += w_step;
                 }
                 kstep(std::integral_constant<int, 1>());
-                xt += BK * 4;
+                xt += 128;
                 wt += w_step;
             }
         } else {
@@ -443,6 +490,8 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
             }
         }
 #undef TSC_MFMA_S
+#undef TSC_MFMA_B
+#undef TSC_MFMA_BALL
 #undef TSC_MFMA
 
         // ---------------------------------------------------------------- epilogues
@@ -710,15 +759,27 @@ int launch(EncodeArgs a, hipStream_t stream) {
     const long long grid = (long long)a.n_tiles_n * a.m_split;
     if (grid <= 0 || grid > 0x7fffffffLL) return tsc_fail(TSC_ERR_ARG, "encode grid %lld out of range", grid);
     const bool dma = a.K % (2 * BK) == 0 && a.bias && use_dma();
-    if (dma && MODE == TSC_MODE_TOPK && C::LDS_LISTS && a.topk <= KL && use_lds_lists())
-        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, MODE == TSC_MODE_TOPK && C::LDS_LISTS>), dim3((unsigned)grid),
-                           dim3(NT), 0, stream, a);
+    const dim3 g((unsigned)grid), b(NT);
+    constexpr bool TK = MODE == TSC_MODE_TOPK && C::LDS_LISTS;
+    const bool lists = TK && a.topk <= KL && use_lds_lists();
+    if (a.bf16) {
+        if (a.K % 128 != 0 || !a.bias) return tsc_fail(TSC_ERR_UNSUPPORTED, "bf16 encode needs d_in %% 128 == 0");
+        if constexpr (C::OCC == 2) {  // the bf16 operands use the 128x128 geometry only
+            if (lists)
+                hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, TK, true>), g, b, 0, stream, a);
+            else
+                hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, false, true>), g, b, 0, stream, a);
+        } else {
+            return tsc_fail(TSC_ERR_UNSUPPORTED, "no bf16 kernel for this tile geometry");
+        }
+    } else if (dma && lists)
+        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, TK, false>), g, b, 0, stream, a);
     else if (dma)
-        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, false>), dim3((unsigned)grid), dim3(NT), 0, stream, a);
+        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, false, false>), g, b, 0, stream, a);
     else if (a.K % BK == 0)
-        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, false, false>), dim3((unsigned)grid), dim3(NT), 0, stream, a);
+        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, false, false, false>), g, b, 0, stream, a);
     else
-        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, false, false, false>), dim3((unsigned)grid), dim3(NT), 0, stream, a);
+        hipLaunchKernelGGL((encode_f32_kernel<C, MODE, false, false, false, false>), g, b, 0, stream, a);
     TSC_HIP_CHECK(hipGetLastError());
     return TSC_OK;
 }
@@ -756,6 +817,7 @@ int tsc_launch_fold_bias(const float *W, const float *b_enc, const float *b_dec,
 // a.m_split <= 0 asks for the balanced split; a.n_tiles_n is filled in here
 int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream) {
     if (a.M <= 0) return TSC_OK;
+    if (a.bf16) return dispatch<CfgSmall>(mode, a, stream);  // one geometry for the bf16 operands
     return use_large_tile() ? dispatch<CfgLarge>(mode, a, stream) : dispatch<CfgSmall>(mode, a, stream);
 }
 

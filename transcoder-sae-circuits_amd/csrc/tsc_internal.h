@@ -9,7 +9,8 @@
 struct tsc_dict {
     int d_in, d_sae, d_out, compute_dtype;
     const float *W_enc, *b_enc, *b_dec, *W_dec, *out_bias;  // borrowed, device
-    void *W_enc_bf16;                                       // owned (TSC_BF16 only): [d_sae/32][d_in/8][32][8] bf16
+    void *W_enc_bf16;                                       // owned (TSC_BF16 only): bf16(W_enc) transposed, [d_sae][d_in]
+    void *x_bf16;                                           // owned (TSC_BF16 only): bf16(x - b_dec) of one chunk of rows
     float *bias_fold;                                       // owned: b_enc - b_dec @ W_enc (fp64 sums), [d_sae]
 };
 
@@ -27,6 +28,7 @@ int tsc_fail(int code, const char *fmt, ...);
 enum { TSC_MODE_DENSE = 0, TSC_MODE_TOPK = 1, TSC_MODE_SPARSE = 2 };
 struct EncodeArgs {
     const float *x, *W, *b_enc, *b_dec;
+    int bf16;            // x and W are the bf16 operands prepared by encode_bf16.hip (see tsc_launch_encode_bf16)
     const float *bias;   // b_enc - b_dec @ W_enc, or null: selects the LDS-DMA kernel when K % 64 == 0
     long long M;
     int K, N;
@@ -45,7 +47,8 @@ int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream);  /
 int tsc_encode_f32_recommended_slots(int d_sae);
 int tsc_launch_fold_bias(const float *W, const float *b_enc, const float *b_dec, int K, int N, float *out,
                          hipStream_t stream);
-int tsc_launch_encode_bf16(int mode, const EncodeArgs &a, const void *W_bf16, hipStream_t stream);
+int tsc_launch_encode_bf16(int mode, const EncodeArgs &a, const void *W_bf16, void *x_bf16, hipStream_t stream);
+size_t tsc_bf16_workspace_bytes(int K);
 int tsc_pack_w_bf16(const float *W, int K, int N, void *dst, hipStream_t stream);
 
 // topk_merge.hip
