@@ -33,8 +33,13 @@ g = torch.Generator(device=dev).manual_seed(3)
 xs = [torch.randn(args.tokens, 768, generator=g, device=dev) for _ in range(args.launches)]
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+_lib = tsc_hip.lib()
 for i, x in enumerate(xs):
     if i == args.launches // 2:
+        if hasattr(_lib, "tsc_debug_read_stamps"):  # count the timed half only
+            import ctypes
+            torch.cuda.synchronize()
+            _lib.tsc_debug_read_stamps((ctypes.c_ulonglong * 16)(), 1)
         e0.record()
     if args.mode == "topk":
         d.encode_topk(x, i * args.tokens, st)

@@ -32,7 +32,7 @@ int check_dict_x(const tsc_dict_t *d, const float *x, int64_t M) {
 EncodeArgs base_args(const tsc_dict_t *d, const float *x, int64_t M) {
     EncodeArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = x; a.W = d->W_enc; a.b_enc = d->b_enc; a.b_dec = d->b_dec; a.bias = d->bias_fold;
+    a.x = x; a.W = d->W_enc; a.b_enc = d->b_enc; a.b_dec = d->b_dec; a.bias = d->bias_fold; a.Wt = d->W_enc_t;
     a.M = M; a.K = d->d_in; a.N = d->d_sae;
     a.m_split = 0;  // the launcher picks the tile geometry and the balanced split
     return a;
@@ -82,9 +82,12 @@ int tsc_dict_create(tsc_dict_t **out, int d_in, int d_sae, int d_out, int comput
         }
     }
     {
-        hipError_t e = hipMalloc((void **)&d->bias_fold, (size_t)d_sae * sizeof(float));
+        hipError_t e = hipSuccess;
+        if (compute_dtype == TSC_F32 && d_in % 64 == 0)  // operand of the LDS-DMA kernel; other d_in use register staging
+            e = hipMalloc((void **)&d->W_enc_t, (size_t)d_in * d_sae * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&d->bias_fold, (size_t)d_sae * sizeof(float));
         int rc = e == hipSuccess ? tsc_dict_refresh(d, stream)
-                                 : tsc_fail(TSC_ERR_HIP, "hipMalloc of the folded bias failed: %s", hipGetErrorString(e));
+                                 : tsc_fail(TSC_ERR_HIP, "hipMalloc of the handle's derived operands failed: %s", hipGetErrorString(e));
         if (rc != TSC_OK) {
             tsc_dict_destroy(d);
             return rc;
@@ -101,6 +104,10 @@ int tsc_dict_refresh(tsc_dict_t *d, tsc_stream_t stream) {
         int rc = tsc_pack_w_bf16(d->W_enc, d->d_in, d->d_sae, d->W_enc_bf16, s);
         if (rc != TSC_OK) return rc;
     }
+    if (d->W_enc_t) {
+        int rc = tsc_transpose_w_f32(d->W_enc, d->d_in, d->d_sae, d->W_enc_t, s);
+        if (rc != TSC_OK) return rc;
+    }
     return tsc_launch_fold_bias(d->W_enc, d->b_enc, d->b_dec, d->d_in, d->d_sae, d->bias_fold, s);
 }
 
@@ -108,6 +115,7 @@ int tsc_dict_destroy(tsc_dict_t *d) {
     if (!d) return TSC_OK;
     if (d->W_enc_bf16) (void)hipFree(d->W_enc_bf16);
     if (d->x_bf16) (void)hipFree(d->x_bf16);
+    if (d->W_enc_t) (void)hipFree(d->W_enc_t);
     if (d->bias_fold) (void)hipFree(d->bias_fold);
     delete d;
     return TSC_OK;

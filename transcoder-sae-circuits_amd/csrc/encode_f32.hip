@@ -216,17 +216,11 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
     const unsigned bd_voff = (unsigned)a_col * 4u;
     if constexpr (DMA) {
 #pragma unroll
-        for (int j = 0; j < BPW; ++j) {
-            if constexpr (BF16) {  // rows are features; same piece shape and swizzle as the x tile
-                const int row = (wave * BPW + j) * 8 + (lane >> 3);
-                const int c = (lane & 7) ^ ((row >> 1) & 7);
-                const int n = n0 + row < a.N ? n0 + row : a.N - 1;
-                b_voff[j] = (unsigned)n * (unsigned)a.K * 2u + (unsigned)c * 16u;
-            } else {
-                const int f = (wave * BPW + j) * 256 + lane * 4;
-                const int col = n0 + f % BN;
-                b_voff[j] = ((unsigned)(f / BN) * (unsigned)a.N + (unsigned)(col < a.N - 4 ? col : a.N - 4)) * 4u;
-            }
+        for (int j = 0; j < BPW; ++j) {  // rows of the W tile are features: same piece shape and swizzle as the x tile
+            const int row = (wave * BPW + j) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const int n = n0 + row < a.N ? n0 + row : a.N - 1;
+            b_voff[j] = (unsigned)n * (unsigned)a.K * (unsigned)ES + (unsigned)c * 16u;
         }
     } else {
         const int nc = n0 + b_col < a.N - 4 ? n0 + b_col : a.N - 4;
@@ -317,7 +311,7 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
                                            (DMA ? (((kk * 2 + lh) ^ ((li >> 1) & 7)) * 4) : kk * 8 + lh * 4)];
 #pragma unroll
         for (int bn = 0; bn < WNB; ++bn) {
-            if constexpr (BF16) {
+            if constexpr (DMA) {
                 f.bf[bn] = *(const f32x4 *)&Bs[(wn0 + bn * 32 + li) * BK + (((kk * 2 + lh) ^ ((li >> 1) & 7)) * 4)];
             } else {
 #pragma unroll
@@ -336,7 +330,7 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
         if constexpr (DMA) {
             const char *xt = (const char *)a.x + (size_t)mt * BM * a.K * ES;
 #pragma unroll
-            for (int j = 0; j < APW + BPW; ++j) dma_piece(j, xt, (const char *)a.W, 0, lds_a0, lds_b0);
+            for (int j = 0; j < APW + BPW; ++j) dma_piece(j, xt, (const char *)a.Wt, 0, lds_a0, lds_b0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             gload(mt * BM, 0);
@@ -382,9 +376,8 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
             constexpr int PPS = (APW + BPW) / 8;
             const bool has_next = mt + a.m_split < n_mtiles;
             const long long next_m0 = has_next ? (mt + a.m_split) * BM : m0;
-            const size_t w_step = BF16 ? 128 : (size_t)BK * a.N * 4;
             const char *xt = (const char *)a.x + (size_t)m0 * a.K * ES + 128;  // k-step 1 of this tile
-            const char *wt = (const char *)a.W + w_step;
+            const char *wt = (const char *)a.Wt + 128;
             auto kstep = [&](auto par_) {
                 constexpr int PAR = decltype(par_)::value;
                 // keep the tile bases in scalar registers (saddr + 32-bit lane offset addressing);
@@ -453,14 +446,14 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
                 if (kt + 2 == nk) {
                     set_tile(next_m0);
                     xt = (const char *)a.x + (size_t)next_m0 * a.K * ES;
-                    wt = (const char *)a.W;
+                    wt = (const char *)a.Wt;
                 } else {
                     xt += 128;
-                    wt += w_step;
+                    wt += 128;
                 }
                 kstep(std::integral_constant<int, 1>());
                 xt += 128;
-                wt += w_step;
+                wt += 128;
             }
         } else {
             for (int kt = 0; kt < nk; ++kt) {
@@ -758,12 +751,12 @@ int launch(EncodeArgs a, hipStream_t stream) {
         a.m_split = balanced_split(a.n_tiles_n, (a.M + C::BM - 1) / C::BM, 256 * C::OCC, 64);
     const long long grid = (long long)a.n_tiles_n * a.m_split;
     if (grid <= 0 || grid > 0x7fffffffLL) return tsc_fail(TSC_ERR_ARG, "encode grid %lld out of range", grid);
-    const bool dma = a.K % (2 * BK) == 0 && a.bias && use_dma();
+    const bool dma = a.K % (2 * BK) == 0 && a.bias && a.Wt && use_dma();
     const dim3 g((unsigned)grid), b(NT);
     constexpr bool TK = MODE == TSC_MODE_TOPK && C::LDS_LISTS;
     const bool lists = TK && a.topk <= KL && use_lds_lists();
     if (a.bf16) {
-        if (a.K % 128 != 0 || !a.bias) return tsc_fail(TSC_ERR_UNSUPPORTED, "bf16 encode needs d_in %% 128 == 0");
+        if (a.K % 128 != 0 || !a.bias || !a.Wt) return tsc_fail(TSC_ERR_UNSUPPORTED, "bf16 encode needs d_in %% 128 == 0");
         if constexpr (C::OCC == 2) {  // the bf16 operands use the 128x128 geometry only
             if (lists)
                 hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, TK, true>), g, b, 0, stream, a);

@@ -1,3 +1,9 @@
+// Operand preparation for the LDS-DMA encode kernels (encode_f32.hip).
+//
+// fp32: the handle keeps W_enc transposed, [d_sae][d_in], so that a feature's k run is contiguous: the W tile
+// is then staged by the same 8-rows-by-128-bytes DMA pieces as the x tile and a B fragment is one
+// ds_read_b128 (transpose_w_kernel, at tsc_dict_create / tsc_dict_refresh).
+//
 // bf16 encode path (TSC_BF16 dictionaries; BASELINE config 5, the wide-dictionary stress case).
 //
 //   acts = relu( bf16(x - b_dec) @ bf16(W_enc) + b_enc ),  products exact, fp32 accumulation
@@ -35,6 +41,19 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const float *__restrict__ W
     *(uint4 *)(out + (size_t)n * K + k0) = u.v;
 }
 
+// out[n][k0..k0+7] = W[k0..k0+7][n]
+__global__ __launch_bounds__(256) void transpose_w_kernel(const float *__restrict__ W, int K, int N,
+                                                         float *__restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int k0 = blockIdx.y * 8;
+    if (n >= N) return;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = W[(size_t)(k0 + j) * N + n];
+    *(float4 *)(out + (size_t)n * K + k0) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4 *)(out + (size_t)n * K + k0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
 // out[m][k] = bf16(x[m][k] - b_dec[k]); 8 elements per thread
 __global__ __launch_bounds__(256) void convert_x_kernel(const float *__restrict__ x, const float *__restrict__ b_dec,
                                                        long long n8, int K8, unsigned short *__restrict__ out) {
@@ -63,6 +82,13 @@ int tsc_pack_w_bf16(const float *W, int K, int N, void *dst, hipStream_t stream)
     return TSC_OK;
 }
 
+int tsc_transpose_w_f32(const float *W, int K, int N, float *dst, hipStream_t stream) {
+    if (K % 8) return tsc_fail(TSC_ERR_UNSUPPORTED, "W_enc transpose needs d_in %% 8 == 0");
+    hipLaunchKernelGGL(transpose_w_kernel, dim3((N + 255) / 256, K / 8), dim3(256), 0, stream, W, K, N, dst);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
 int tsc_launch_encode_bf16(int mode, const EncodeArgs &a, const void *W_bf16, void *x_bf16, hipStream_t stream) {
     if (!W_bf16 || !x_bf16) return tsc_fail(TSC_ERR_ARG, "bf16 handle without its operand buffers");
     for (long long r0 = 0; r0 < a.M; r0 += TSC_BF16_WS_ROWS) {
@@ -74,7 +100,7 @@ int tsc_launch_encode_bf16(int mode, const EncodeArgs &a, const void *W_bf16, vo
         EncodeArgs c = a;
         c.bf16 = 1;
         c.x = (const float *)x_bf16;
-        c.W = (const float *)W_bf16;
+        c.Wt = W_bf16;
         c.bias = a.b_enc;  // b_dec is already subtracted
         c.M = rows;
         c.token_base = a.token_base + r0;

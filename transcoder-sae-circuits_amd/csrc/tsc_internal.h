@@ -9,6 +9,7 @@
 struct tsc_dict {
     int d_in, d_sae, d_out, compute_dtype;
     const float *W_enc, *b_enc, *b_dec, *W_dec, *out_bias;  // borrowed, device
+    float *W_enc_t;                                         // owned (d_in % 64 == 0): W_enc transposed, [d_sae][d_in]
     void *W_enc_bf16;                                       // owned (TSC_BF16 only): bf16(W_enc) transposed, [d_sae][d_in]
     void *x_bf16;                                           // owned (TSC_BF16 only): bf16(x - b_dec) of one chunk of rows
     float *bias_fold;                                       // owned: b_enc - b_dec @ W_enc (fp64 sums), [d_sae]
@@ -28,7 +29,8 @@ int tsc_fail(int code, const char *fmt, ...);
 enum { TSC_MODE_DENSE = 0, TSC_MODE_TOPK = 1, TSC_MODE_SPARSE = 2 };
 struct EncodeArgs {
     const float *x, *W, *b_enc, *b_dec;
-    int bf16;            // x and W are the bf16 operands prepared by encode_bf16.hip (see tsc_launch_encode_bf16)
+    const void *Wt;      // W_enc transposed, [N][K] (fp32, or bf16 when .bf16): the LDS-DMA kernels' W operand
+    int bf16;            // x and Wt are the bf16 operands prepared by encode_operands.hip (see tsc_launch_encode_bf16)
     const float *bias;   // b_enc - b_dec @ W_enc, or null: selects the LDS-DMA kernel when K % 64 == 0
     long long M;
     int K, N;
@@ -50,6 +52,7 @@ int tsc_launch_fold_bias(const float *W, const float *b_enc, const float *b_dec,
 int tsc_launch_encode_bf16(int mode, const EncodeArgs &a, const void *W_bf16, void *x_bf16, hipStream_t stream);
 size_t tsc_bf16_workspace_bytes(int K);
 int tsc_pack_w_bf16(const float *W, int K, int N, void *dst, hipStream_t stream);
+int tsc_transpose_w_f32(const float *W, int K, int N, float *dst, hipStream_t stream);
 
 // topk_merge.hip
 int tsc_launch_topk_fill(float *vals, long long *idx, long long n, hipStream_t stream);
