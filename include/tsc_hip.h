@@ -79,6 +79,10 @@ int tsc_encode_dense(const tsc_dict_t *dict, const float *x, int64_t M, float *o
  * over n_slots groups of workgroups so that no two workgroups ever touch one list, and
  * tsc_topk_finalize merges the slots.  tsc_topk_recommended_slots(d_sae) returns the slot count
  * that fills the chip evenly (any n_slots >= 1 is correct).
+ * floor (optional, may be NULL): [d_sae] fp32 scratch.  When given and n_slots > 1, tsc_encode_topk first
+ * writes each feature's current k-th best value over ALL slots into it and the encode kernel dismisses
+ * candidates below it -- they cannot be in the merged result -- instead of only those below the k-th best
+ * of their own slot (n_slots times fewer list updates).  Its contents carry nothing between calls.
  */
 typedef struct {
     float *vals;   /* device */
@@ -86,6 +90,8 @@ typedef struct {
     int32_t d_sae;
     int32_t k;       /* 1..64 */
     int32_t n_slots; /* 1..64 */
+    int32_t reserved;
+    float *floor;  /* device, [d_sae] scratch, or NULL */
 } tsc_topk_state_t;
 
 int tsc_topk_recommended_slots(int d_sae);

@@ -17,6 +17,7 @@ ap.add_argument("--launches", type=int, default=12)
 ap.add_argument("--mode", default="topk", choices=["topk", "dense", "sparse"])
 ap.add_argument("--slots", type=int, default=0)
 ap.add_argument("--bf16", action="store_true")
+ap.add_argument("--no-floor", action="store_true", help="without the cross-slot k-th-best floor")
 ap.add_argument("--b-enc", type=float, default=None, help="override b_enc (e.g. -100: nothing is ever active)")
 args = ap.parse_args()
 
@@ -28,7 +29,7 @@ W, be, bd = make_device_dictionary(args.d_sae, 1, dev)
 if args.b_enc is not None:
     be.fill_(args.b_enc)
 d = tsc_hip.DeviceDict(W, be, bd, compute_dtype=tsc_hip.BF16 if args.bf16 else tsc_hip.F32)
-st = tsc_hip.TopkState(args.d_sae, 20, dev, n_slots=args.slots or None)
+st = tsc_hip.TopkState(args.d_sae, 20, dev, n_slots=args.slots or None, cross_slot_floor=not args.no_floor)
 g = torch.Generator(device=dev).manual_seed(3)
 xs = [torch.randn(args.tokens, 768, generator=g, device=dev) for _ in range(args.launches)]
 torch.cuda.synchronize()

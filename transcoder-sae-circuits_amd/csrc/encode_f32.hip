@@ -69,6 +69,7 @@ struct __attribute__((aligned(16))) Smem {
     float f_worst_v[C::BN];
     unsigned char f_worst_pos[C::BN];  // k <= 64
     unsigned char f_cnt[C::BN];
+    float f_floor[C::BN];  // k-th best of the feature over all slots when the launch started (0: unknown)
     int pushed, again;  // round flags: somebody pushed / somebody found its feature's slots full
     int pad[2];
 };
@@ -188,7 +189,9 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
             sm.f_worst_pos[tid] = wpos;
             sm.f_worst_v[tid] = wv;
             sm.f_worst_id[tid] = wid;
-            sm.thr[tid] = cnt == a.topk ? wv : 0.f;
+            const float fl = a.tk_floor && n0 + tid < a.N ? a.tk_floor[n0 + tid] : 0.f;
+            sm.f_floor[tid] = fl;
+            sm.thr[tid] = fmaxf(cnt == a.topk ? wv : 0.f, fl);
         }
         if (tid < BN) sm.f_nq[tid] = 0;
         if (tid == 0) sm.pushed = sm.again = 0;
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
                     sm.f_worst_pos[tid] = wpos;
                     sm.f_worst_v[tid] = wv;
                     sm.f_worst_id[tid] = wid;
-                    sm.thr[tid] = cnt == k ? wv : 0.f;
+                    sm.thr[tid] = fmaxf(cnt == k ? wv : 0.f, sm.f_floor[tid]);
                 }
                 if (tid < BN) sm.f_nq[tid] = 0;
                 TSC_STAMP(4)

@@ -18,6 +18,36 @@ __global__ void topk_fill_kernel(float *vals, long long *idx, long long n) {
     }
 }
 
+// floor[f] = the k-th largest value over the feature's n_slots unsorted lists (0 while fewer than k entries
+// are live: padding is 0 and live values are > 0).  One thread per feature keeps the KC largest values seen
+// in registers with a branch-free insertion (max/min ripple); values only, no ids: a candidate below the
+// floor cannot enter the merged top-k whatever the tie rule.
+template <int KC>
+__global__ __launch_bounds__(128) void topk_floor_kernel(const float *__restrict__ vals, int n_slots, int d_sae,
+                                                         int k, float *__restrict__ floor) {
+    const int f = blockIdx.x * 128 + threadIdx.x;
+    if (f >= d_sae) return;
+    float t[KC];
+#pragma unroll
+    for (int j = 0; j < KC; ++j) t[j] = 0.f;
+    for (int s = 0; s < n_slots; ++s) {
+        const float *l = vals + ((size_t)s * d_sae + f) * k;
+        for (int i = 0; i < k; ++i) {
+            float v = l[i];
+#pragma unroll
+            for (int j = 0; j < KC; ++j) {
+                const float hi = fmaxf(t[j], v);
+                v = fminf(t[j], v);
+                t[j] = hi;
+            }
+        }
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) r = j == k - 1 ? t[j] : r;
+    floor[f] = r;
+}
+
 __device__ __forceinline__ bool ranks_above(float v, long long id, float w, long long wid) {
     return v > w || (v == w && id < wid);
 }
@@ -77,6 +107,20 @@ int tsc_launch_topk_fill(float *vals, long long *idx, long long n, hipStream_t s
     long long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(topk_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, vals, idx, n);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
+int tsc_launch_topk_floor(const float *vals, int n_slots, int d_sae, int k, float *floor, hipStream_t stream) {
+    const dim3 g((d_sae + 127) / 128), b(128);
+    if (k <= 8)
+        hipLaunchKernelGGL(topk_floor_kernel<8>, g, b, 0, stream, vals, n_slots, d_sae, k, floor);
+    else if (k <= 20)
+        hipLaunchKernelGGL(topk_floor_kernel<20>, g, b, 0, stream, vals, n_slots, d_sae, k, floor);
+    else if (k <= 32)
+        hipLaunchKernelGGL(topk_floor_kernel<32>, g, b, 0, stream, vals, n_slots, d_sae, k, floor);
+    else
+        hipLaunchKernelGGL(topk_floor_kernel<64>, g, b, 0, stream, vals, n_slots, d_sae, k, floor);
     TSC_HIP_CHECK(hipGetLastError());
     return TSC_OK;
 }

@@ -38,6 +38,7 @@ struct EncodeArgs {
     float *out;          // DENSE
     float *tk_vals;      // TOPK: [m_split][N][topk]
     long long *tk_idx;   //
+    const float *tk_floor;  // [N] or null: k-th best over all slots at launch time
     int topk;
     long long token_base;
     int *sp_feat;        // SPARSE: [M][max_active]
@@ -56,6 +57,7 @@ int tsc_transpose_w_f32(const float *W, int K, int N, float *dst, hipStream_t st
 
 // topk_merge.hip
 int tsc_launch_topk_fill(float *vals, long long *idx, long long n, hipStream_t stream);
+int tsc_launch_topk_floor(const float *vals, int n_slots, int d_sae, int k, float *floor, hipStream_t stream);
 int tsc_launch_topk_merge(const float *vals, const long long *idx, int n_lists, int d_sae, int k,
                           float *out_vals, long long *out_idx, hipStream_t stream);
 

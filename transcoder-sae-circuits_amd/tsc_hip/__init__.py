@@ -55,7 +55,7 @@ class TscError(RuntimeError):
 
 class _TopkStateStruct(ctypes.Structure):
     _fields_ = [("vals", _c.c_void_p), ("idx", _c.c_void_p), ("d_sae", _c.c_int32), ("k", _c.c_int32),
-                ("n_slots", _c.c_int32)]
+                ("n_slots", _c.c_int32), ("reserved", _c.c_int32), ("floor", _c.c_void_p)]
 
 
 def library_path() -> str:
@@ -225,7 +225,8 @@ class DeviceDict:
 class TopkState:
     """Caller-owned running top-k lists: ``vals [n_slots, d_sae, k]`` fp32 and ``idx`` int64."""
 
-    def __init__(self, d_sae: int, k: int = 20, device="cuda", n_slots: Optional[int] = None):
+    def __init__(self, d_sae: int, k: int = 20, device="cuda", n_slots: Optional[int] = None,
+                 cross_slot_floor: bool = True):
         if n_slots is None:
             n_slots = lib().tsc_topk_recommended_slots(d_sae)
         self.d_sae, self.k, self.n_slots = int(d_sae), int(k), int(n_slots)
@@ -234,7 +235,10 @@ class TopkState:
             raise TscError("top-k state must live on the GPU")
         self.vals = torch.empty(self.n_slots, d_sae, k, dtype=torch.float32, device=self.device)
         self.idx = torch.empty(self.n_slots, d_sae, k, dtype=torch.int64, device=self.device)
-        self._struct = _TopkStateStruct(self.vals.data_ptr(), self.idx.data_ptr(), d_sae, k, self.n_slots)
+        # scratch for the k-th best over all slots (see include/tsc_hip.h); not part of the state's content
+        self.floor = torch.zeros(d_sae, dtype=torch.float32, device=self.device) if cross_slot_floor else None
+        self._struct = _TopkStateStruct(self.vals.data_ptr(), self.idx.data_ptr(), d_sae, k, self.n_slots, 0,
+                                        self.floor.data_ptr() if cross_slot_floor else None)
         self.reset()
 
     def reset(self) -> None:
