@@ -108,7 +108,10 @@ __global__ __launch_bounds__(256) void decode_sparse_kernel(const float *W_dec, 
     }
 }
 
-// one wavefront per (token, active slot) pair; directions staged in LDS once per block
+// Workgroups walk tokens; the directions are staged in LDS once per workgroup.  A quarter wave (16 lanes)
+// takes one active feature: its W_dec row is read as 16-lane x 16-byte runs with all of a lane's loads in
+// flight at once (12 for d_out = 768), dotted against every direction, and reduced over 16 lanes.  Only the
+// token's `count` live entries are visited; the tail of its score row is zero-filled.
 template <int NDIR>
 __global__ __launch_bounds__(256) void contrib_kernel(const float *W_dec, int d_out, const int *feat,
                                                      const float *val, const int *count, long long M,
@@ -118,41 +121,48 @@ __global__ __launch_bounds__(256) void contrib_kernel(const float *W_dec, int d_
     const int chunks = d_out >> 2;
     for (int i = threadIdx.x; i < NDIR * chunks; i += blockDim.x) sd[i] = ((const f32x4 *)dirs)[i];
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
-    const long long total = M * max_active;
-    for (long long p = wave; p < total; p += n_waves) {
-        const long long m = p / max_active;
-        const int i = (int)(p - m * max_active);
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;  // 16 groups of 16 lanes
+    for (long long m = blockIdx.x; m < M; m += gridDim.x) {
         int c = count[m];
         if (c > max_active) c = max_active;
-        float part[NDIR];
+        const long long base = m * max_active;
+        for (int e = grp; e < c; e += 16) {
+            const float v = val[base + e];
+            const f32x4 *src = (const f32x4 *)(W_dec + (long long)feat[base + e] * d_out);
+            float part[NDIR];
 #pragma unroll
-        for (int d = 0; d < NDIR; ++d) part[d] = 0.f;
-        float v = 0.f;
-        if (i < c) {  // wave-uniform
-            v = val[p];
-            const f32x4 *src = (const f32x4 *)(W_dec + (long long)feat[p] * d_out);
-            for (int ch = lane; ch < chunks; ch += 64) {
-                const f32x4 w = src[ch];
+            for (int d = 0; d < NDIR; ++d) part[d] = 0.f;
+            for (int ch0 = 0; ch0 < chunks; ch0 += 16 * 12) {
+                f32x4 w[12];
 #pragma unroll
-                for (int d = 0; d < NDIR; ++d) {
-                    const f32x4 q = sd[d * chunks + ch];
-                    part[d] += w.x * q.x + w.y * q.y + w.z * q.z + w.w * q.w;
+                for (int j = 0; j < 12; ++j) {
+                    const int ch = ch0 + l16 + 16 * j;
+                    w[j] = ch < chunks ? src[ch] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int j = 0; j < 12; ++j) {
+                    const int ch = ch0 + l16 + 16 * j;
+                    if (ch < chunks) {
+#pragma unroll
+                        for (int d = 0; d < NDIR; ++d) {
+                            const f32x4 q = sd[d * chunks + ch];
+                            part[d] += w[j].x * q.x + w[j].y * q.y + w[j].z * q.z + w[j].w * q.w;
+                        }
+                    }
                 }
             }
 #pragma unroll
             for (int d = 0; d < NDIR; ++d)
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) part[d] += __shfl_xor(part[d], off);
-        }
-        if (lane < NDIR) {
-            float s = 0.f;
+                for (int off = 8; off > 0; off >>= 1) part[d] += __shfl_xor(part[d], off);
+            if (l16 < NDIR) {
+                float s = 0.f;
 #pragma unroll
-            for (int d = 0; d < NDIR; ++d) s = lane == d ? part[d] : s;
-            scores[p * NDIR + lane] = s * v;
+                for (int d = 0; d < NDIR; ++d) s = l16 == d ? part[d] : s;
+                scores[(base + e) * NDIR + l16] = s * v;
+            }
         }
+        for (int i = c * NDIR + threadIdx.x; i < max_active * NDIR; i += blockDim.x) scores[base * NDIR + i] = 0.f;
     }
 }
 
@@ -202,10 +212,7 @@ __global__ __launch_bounds__(256) void project_kernel(const float *x, long long 
 template <int NDIR>
 int launch_contrib(const float *W_dec, int d_out, const int *feat, const float *val, const int *count,
                    long long M, int max_active, const float *dirs, float *scores, hipStream_t stream) {
-    const long long pairs = M * max_active;
-    long long blocks = (pairs + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
+    long long blocks = M < 4096 ? M : 4096;
     const size_t lds = (size_t)NDIR * d_out * sizeof(float);
     hipLaunchKernelGGL(contrib_kernel<NDIR>, dim3((unsigned)blocks), dim3(256), lds, stream, W_dec, d_out,
                        feat, val, count, M, max_active, dirs, scores);
