@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--cpu-tokens", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0, collectives over gloo
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,13 +96,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", 0 if args.rehearse_on_one_gpu else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse_on_one_gpu:
+            import datetime
+
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     import tsc_hip
 
@@ -136,7 +143,11 @@ def main():
 
             merged = []
             for vals, idx in outs:
-                merged.append(allgather_merge(vals, idx, tsc_hip.topk_merge))
+                if args.rehearse_on_one_gpu:  # gloo moves host tensors; the merge still runs on the device
+                    merged.append(allgather_merge(vals.cpu(), idx.cpu(),
+                                                  lambda v, i: tsc_hip.topk_merge(v.to(device), i.to(device))))
+                else:
+                    merged.append(allgather_merge(vals, idx, tsc_hip.topk_merge))
             outs = merged
         return outs
 
@@ -163,7 +174,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if args.rehearse_on_one_gpu else device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
