@@ -63,6 +63,31 @@ def _g2_setup(kind="mlp"):
     return g, w, xs, n_seq, n_pos, model, tc
 
 
+def test_in_place_weight_updates_are_seen():
+    """The handle caches operands derived from the weights (folded bias, transposed W_enc, the bf16
+    copy); an optimiser-style in-place update of the parameters must show in the next encode."""
+    from load_model_and_encoders import build_transcoder
+
+    g, wt, wz, x = gi.g1_inputs()
+    tc = build_transcoder(wt, 8, DEV)
+    _close(tc.encode(x), g["tc_encode"])
+    w2 = {k: v.clone() for k, v in wt.items()}
+    gen = torch.Generator().manual_seed(9)
+    w2["b_dec"] += 0.3 * torch.randn(768, generator=gen)
+    w2["b_enc"] += 0.1
+    w2["W_enc"] *= 1.0 + 0.05 * torch.randn(768, 1, generator=gen)
+    tc.b_dec.add_(w2["b_dec"].to(DEV) - tc.b_dec)          # same storage, new values
+    tc.b_enc.copy_(w2["b_enc"].to(DEV))
+    tc.W_enc.mul_((w2["W_enc"] / wt["W_enc"]).to(DEV))
+    ref = E.encode_ref(x, w2["W_enc"], w2["b_enc"], w2["b_dec"])
+    assert not torch.allclose(ref, torch.as_tensor(g["tc_encode"]), atol=1e-2)
+    _close(tc.encode(x), ref)
+    st = tc.new_topk_state(k=4)
+    tc.encode_topk(x, 0, st)
+    v, _ = st.finalize()
+    _close(v[:, 0], ref.max(dim=0).values)
+
+
 def test_max_act_analysis_active_examples():
     from max_act_analysis import MaxActAnalysis
 
