@@ -52,6 +52,61 @@ __device__ __forceinline__ bool ranks_above(float v, long long id, float w, long
     return v > w || (v == w && id < wid);
 }
 
+// Register variant for n_lists * k <= 64 * EPL: one wavefront per feature (4 features per workgroup), every
+// lane keeps EPL entries in registers; k rounds of (lane-local best, wave arg-max by shuffles, retire the
+// winner).  No LDS, no barrier.
+template <int EPL>
+__global__ __launch_bounds__(256) void topk_merge_reg_kernel(const float *__restrict__ vals,
+                                                            const long long *__restrict__ idx, int n_lists,
+                                                            int d_sae, int k, float *__restrict__ out_vals,
+                                                            long long *__restrict__ out_idx) {
+    const int lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= d_sae) return;
+    const int total = n_lists * k;
+    float ev[EPL];
+    long long eid[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        const int e = lane + 64 * j;
+        ev[j] = -1.f;
+        eid[j] = -1;
+        if (e < total) {
+            const int l = e / k, i = e - l * k;
+            const long long off = ((long long)l * d_sae + f) * k + i;
+            const long long id = idx[off];
+            const float v = vals[off];
+            if (id >= 0 && v > 0.f) { ev[j] = v; eid[j] = id; }
+        }
+    }
+    for (int round = 0; round < k; ++round) {
+        float bv = -1.f;
+        long long bid = -1;
+        int be = -1;  // global entry number of the lane's best: breaks ties between identical (value, id) pairs
+#pragma unroll
+        for (int j = 0; j < EPL; ++j)
+            if (ev[j] > 0.f && (be < 0 || ranks_above(ev[j], eid[j], bv, bid))) {
+                bv = ev[j]; bid = eid[j]; be = lane + 64 * j;
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const long long oid = __shfl_xor(bid, off);
+            const int oe = __shfl_xor(be, off);
+            const bool take = oe >= 0 && (be < 0 || ranks_above(ov, oid, bv, bid) ||
+                                          (ov == bv && oid == bid && oe < be));
+            if (take) { bv = ov; bid = oid; be = oe; }
+        }
+#pragma unroll
+        for (int j = 0; j < EPL; ++j)
+            if (be == lane + 64 * j) ev[j] = -1.f;
+        if (lane == 0) {
+            out_vals[(long long)f * k + round] = be >= 0 ? bv : 0.f;
+            out_idx[(long long)f * k + round] = be >= 0 ? bid : -1;
+        }
+    }
+}
+
 // grid = d_sae, block = 64.  Entries with id < 0 or value <= 0 are padding.
 __global__ __launch_bounds__(64) void topk_merge_kernel(const float *vals, const long long *idx,
                                                         int n_lists, int d_sae, int k,
@@ -130,8 +185,19 @@ int tsc_launch_topk_merge(const float *vals, const long long *idx, int n_lists, 
     if ((long long)n_lists * k > MERGE_MAX)
         return tsc_fail(TSC_ERR_UNSUPPORTED, "merge of %d lists x k=%d exceeds %d entries per feature",
                         n_lists, k, MERGE_MAX);
-    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)d_sae), dim3(64), 0, stream, vals, idx,
-                       n_lists, d_sae, k, out_vals, out_idx);
+    const int total = n_lists * k;
+    const dim3 g4((d_sae + 3) / 4), b4(256);
+    if (total <= 64)
+        hipLaunchKernelGGL(topk_merge_reg_kernel<1>, g4, b4, 0, stream, vals, idx, n_lists, d_sae, k, out_vals, out_idx);
+    else if (total <= 128)
+        hipLaunchKernelGGL(topk_merge_reg_kernel<2>, g4, b4, 0, stream, vals, idx, n_lists, d_sae, k, out_vals, out_idx);
+    else if (total <= 192)
+        hipLaunchKernelGGL(topk_merge_reg_kernel<3>, g4, b4, 0, stream, vals, idx, n_lists, d_sae, k, out_vals, out_idx);
+    else if (total <= 256)
+        hipLaunchKernelGGL(topk_merge_reg_kernel<4>, g4, b4, 0, stream, vals, idx, n_lists, d_sae, k, out_vals, out_idx);
+    else
+        hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)d_sae), dim3(64), 0, stream, vals, idx,
+                           n_lists, d_sae, k, out_vals, out_idx);
     TSC_HIP_CHECK(hipGetLastError());
     return TSC_OK;
 }
