@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
             const int row = (wave * BPW + j) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
             const int n = n0 + row < a.N ? n0 + row : a.N - 1;
-            b_voff[j] = (unsigned)n * (unsigned)a.K * (unsigned)ES + (unsigned)c * 16u;
+            b_voff[j] = (unsigned)n * (unsigned)a.K * (unsigned)ES + (unsigned)c * 16u + (4096u - (j & 3) * 1024u);
         }
     } else {
         const int nc = n0 + b_col < a.N - 4 ? n0 + b_col : a.N - 4;
@@ -239,7 +239,8 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
             for (int j = 0; j < APW; ++j) {
                 const int row = (wave * APW + j) * 8 + (lane >> 3);
                 const int c = (lane & 7) ^ ((row >> 1) & 7);
-                a_voff[j] = (unsigned)(row < rmax ? row : rmax) * (unsigned)a.K * (unsigned)ES + (unsigned)c * 16u;
+                a_voff[j] = (unsigned)(row < rmax ? row : rmax) * (unsigned)a.K * (unsigned)ES + (unsigned)c * 16u +
+                            (4096u - (j & 3) * 1024u);
             }
         } else {
 #pragma unroll
@@ -253,14 +254,26 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
     // lds_a / lds_b: LDS byte addresses of this wave's first x / W piece in buffer 0.
     const unsigned lds_a0 = (unsigned)(size_t)(lptr_t)&sm.A[0][wave * APW * 256];
     const unsigned lds_b0 = (unsigned)(size_t)(lptr_t)&sm.B[0][wave * BPW * 256];
+    // The instruction's immediate offset applies to the global AND the LDS address: pieces j = 4g .. 4g+3 of an
+    // operand share one LDS base (one M0 write instead of four) and take their 1-KiB stride from the
+    // immediate; the lane offsets carry the opposite bias (4096 - 1024 * (j & 3), against a tile base lowered by
+    // 4096) so that the global address is unchanged.
+#define TSC_GLDS(G, L, Q, AUX)                                                                         \
+    switch (Q) {                                                                                       \
+        case 0: __builtin_amdgcn_global_load_lds(G, L, 16, 0, AUX); break;                             \
+        case 1: __builtin_amdgcn_global_load_lds(G, L, 16, 1024, AUX); break;                          \
+        case 2: __builtin_amdgcn_global_load_lds(G, L, 16, 2048, AUX); break;                          \
+        default: __builtin_amdgcn_global_load_lds(G, L, 16, 3072, AUX); break;                         \
+    }
     auto dma_piece = [&](int j, const char *xt, const char *wt, int buf, unsigned lds_a, unsigned lds_b) {
-        if (j < APW)
-            __builtin_amdgcn_global_load_lds((gptr_t)(xt + a_voff[j]),
-                                             (lptr_t)(size_t)(lds_a + buf * (unsigned)sizeof(sm.A[0]) + j * 1024), 16, 0, TSC_X_AUX);
-        else
-            __builtin_amdgcn_global_load_lds((gptr_t)(wt + b_voff[j - APW]),
-                                             (lptr_t)(size_t)(lds_b + buf * (unsigned)sizeof(sm.B[0]) + (j - APW) * 1024),
-                                             16, 0, TSC_W_AUX);
+        if (j < APW) {
+            TSC_GLDS((gptr_t)(xt - 4096 + a_voff[j]),
+                     (lptr_t)(size_t)(lds_a + buf * (unsigned)sizeof(sm.A[0]) + (j >> 2) * 4096), j & 3, TSC_X_AUX)
+        } else {
+            const int jb = j - APW;
+            TSC_GLDS((gptr_t)(wt - 4096 + b_voff[jb]),
+                     (lptr_t)(size_t)(lds_b + buf * (unsigned)sizeof(sm.B[0]) + (jb >> 2) * 4096), jb & 3, TSC_W_AUX)
+        }
     };
     auto gload = [&](long long m0, int k0) {
         if (KALIGNED) {
