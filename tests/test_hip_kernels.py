@@ -179,12 +179,13 @@ def test_fused_topk_bit_exact_on_duplicated_tokens(k, n_slots, batch):
     d, _ = _dd(w)
     xg = x.to(DEV)
     exp_v, exp_i = _rank_own_dense(d.encode_dense(xg), k, base=50)
-    st = tsc_hip.TopkState(1536, k, DEV, n_slots=n_slots)
-    for s in range(0, xg.shape[0], batch):
-        d.encode_topk(xg[s:s + batch], 50 + s, st)
-    vals, idx = st.finalize()
-    assert torch.equal(vals.cpu(), exp_v)
-    assert torch.equal(idx.cpu(), exp_i)
+    for floor in (True, False):  # with and without the optional cross-slot floor scratch
+        st = tsc_hip.TopkState(1536, k, DEV, n_slots=n_slots, cross_slot_floor=floor)
+        for s in range(0, xg.shape[0], batch):
+            d.encode_topk(xg[s:s + batch], 50 + s, st)
+        vals, idx = st.finalize()
+        assert torch.equal(vals.cpu(), exp_v)
+        assert torch.equal(idx.cpu(), exp_i)
 
 
 BF16_RTOL = 2.0 ** -7  # relative to the fp32 restatement on bf16-rounded operands
