@@ -87,6 +87,39 @@ def test_encode_dense_odd_shapes():
     assert d.encode_dense(torch.empty(0, 100, device=DEV)).shape == (0, 200)
 
 
+@pytest.mark.parametrize("d_in,d_sae,bf16", [(64, 1000, False), (768, 1000, False), (192, 132, False),
+                                             (128, 200, True), (768, 1000, True), (96, 260, False)])
+def test_all_epilogues_on_ragged_dictionary_shapes(d_in, d_sae, bf16):
+    """Shapes that exercise the tails of every kernel variant: d_sae not a multiple of the 128-wide
+    column tile (clamped W rows, masked columns), the shortest k-loops of the LDS-DMA kernels
+    (d_in = 64 / 128), a d_in that falls back to register staging (96), ragged token tiles."""
+    import tsc_hip
+    from synthetic_dicts import make_dictionary_weights
+
+    w = make_dictionary_weights(d_in=d_in, d_sae=d_sae, seed=d_in + d_sae, b_enc=-0.2)
+    d, g = _dd(w, compute_dtype=tsc_hip.BF16 if bf16 else tsc_hip.F32)
+    m = 391
+    x = torch.randn(m, d_in, generator=torch.Generator().manual_seed(d_sae))
+    x[300:330] = x[5:35]
+    ref = (E.encode_bf16_ref if bf16 else E.encode_ref)(x, w["W_enc"], w["b_enc"], w["b_dec"])
+    xg = x.to(DEV)
+    dense = d.encode_dense(xg)
+    _close(dense, ref)
+    k = 9
+    exp_v, exp_i = _rank_own_dense(dense, k, base=3)
+    st = tsc_hip.TopkState(d_sae, k, DEV, n_slots=3)
+    d.encode_topk(xg[:129], 3, st)
+    d.encode_topk(xg[129:], 3 + 129, st)
+    v, i = st.finalize()
+    assert torch.equal(v.cpu(), exp_v) and torch.equal(i.cpu(), exp_i)
+    feat, val, count = d.encode_sparse(xg, 64)
+    assert torch.equal(count.long(), (dense > 0).sum(dim=1))
+    row = 390
+    c = int(count[row])
+    order = torch.sort(dense[row], descending=True, stable=True)
+    assert torch.equal(val[row, :c], order.values[:c]) and torch.equal(feat[row, :c].long(), order.indices[:c])
+
+
 def test_fused_topk_matches_golden():
     import tsc_hip
 
