@@ -95,6 +95,14 @@ typedef struct {
 } tsc_topk_state_t;
 
 int tsc_topk_recommended_slots(int d_sae);
+
+/*
+ * Kernel-variant override for tests and measurements (no reference counterpart; results are identical for
+ * every setting).  key/value: "f32_tile" or "bf16_tile" = 0 (auto) | 128 | 256; "staging" = 0 (auto: LDS-DMA) |
+ * 1 (register staging); "lists" = 0 (auto: list values mirrored in LDS) | 1 (lists in HBM only).
+ * Process-wide; not meant to be changed while calls are in flight.
+ */
+int tsc_set_tuning(const char *key, int value);
 /* Fill every list with the padding entry (0.0, -1). */
 int tsc_topk_state_reset(const tsc_topk_state_t *state, tsc_stream_t stream);
 

@@ -120,6 +120,51 @@ def test_all_epilogues_on_ragged_dictionary_shapes(d_in, d_sae, bf16):
     assert torch.equal(val[row, :c], order.values[:c]) and torch.equal(feat[row, :c].long(), order.indices[:c])
 
 
+_VARIANTS = [
+    {"f32_tile": 128}, {"f32_tile": 256}, {"f32_tile": 128, "lists": 1}, {"f32_tile": 128, "staging": 1},
+    {"f32_tile": 256, "staging": 1}, {"bf16_tile": 128}, {"bf16_tile": 256}, {"bf16_tile": 128, "lists": 1},
+]
+
+
+@pytest.mark.parametrize("variant", _VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
+def test_every_kernel_variant_gives_the_same_results(variant):
+    """Tile geometry, staging mode and list placement are speed choices: forced one at a time
+    (``tsc_set_tuning``), each must reproduce the oracle (dense) and the exact ranking of its own dense
+    activations (fused top-k, sparse emit), on a ragged shape."""
+    import tsc_hip
+    from synthetic_dicts import make_dictionary_weights
+
+    bf16 = any(k.startswith("bf16") for k in variant)
+    w = make_dictionary_weights(d_in=768, d_sae=1000, seed=77, b_enc=-0.9)
+    m = 700
+    x = torch.randn(m, 768, generator=torch.Generator().manual_seed(78))
+    x[500:560] = x[20:80]
+    ref = (E.encode_bf16_ref if bf16 else E.encode_ref)(x, w["W_enc"], w["b_enc"], w["b_dec"])
+    try:
+        for key, value in variant.items():
+            tsc_hip.set_tuning(key, value)
+        d, _ = _dd(w, compute_dtype=tsc_hip.BF16 if bf16 else tsc_hip.F32)
+        xg = x.to(DEV)
+        dense = d.encode_dense(xg)
+        _close(dense, ref)
+        for k, n_slots, cuts in ((20, 2, [0, 300, m]), (33, 3, [0, m])):
+            exp_v, exp_i = _rank_own_dense(dense, k, base=11)
+            st = tsc_hip.TopkState(1000, k, DEV, n_slots=n_slots)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                d.encode_topk(xg[a:b], 11 + a, st)
+            v, i = st.finalize()
+            assert torch.equal(v.cpu(), exp_v) and torch.equal(i.cpu(), exp_i)
+        feat, val, count = d.encode_sparse(xg, 128)
+        assert torch.equal(count.long(), (dense > 0).sum(dim=1))
+        for row in (0, 255, 256, m - 1):
+            c = int(count[row])
+            order = torch.sort(dense[row], descending=True, stable=True)
+            assert torch.equal(val[row, :c], order.values[:c]) and torch.equal(feat[row, :c].long(), order.indices[:c])
+    finally:
+        for key in ("f32_tile", "bf16_tile", "staging", "lists"):
+            tsc_hip.set_tuning(key, 0)
+
+
 def test_fused_topk_matches_golden():
     import tsc_hip
 

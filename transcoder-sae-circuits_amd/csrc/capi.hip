@@ -133,8 +133,10 @@ int tsc_encode_dense(const tsc_dict_t *d, const float *x, int64_t M, float *out,
 
 int tsc_topk_recommended_slots(int d_sae) {
     if (d_sae <= 0) return 1;
-    return tsc_encode_f32_recommended_slots(d_sae);
+    return tsc_encode_recommended_slots(d_sae, 0);
 }
+
+int tsc_set_tuning(const char *key, int value) { return tsc_encode_set_tuning(key, value); }
 
 static int check_state(const tsc_topk_state_t *s) {
     if (!s || !s->vals || !s->idx) return tsc_fail(TSC_ERR_ARG, "null top-k state");

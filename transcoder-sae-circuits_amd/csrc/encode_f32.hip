@@ -25,13 +25,14 @@
 // VALU shares the SIMD's issue with the fp32 MFMA and a wave issues in order, so what decides the
 // rate is the number of non-MFMA instructions per MFMA; the large tile halves it.
 #include <cstdlib>
+#include <string>
 #include <type_traits>
 
 #include "tsc_internal.h"
 
 namespace {
 
-constexpr int BK = 32, NT = 256;
+constexpr int BK = 32;
 constexpr int LDA = BK + 4;  // 144-byte rows: ds_read_b128 of 16 consecutive rows hits 16 distinct slots
 constexpr int QD = 4;   // candidate slots per feature and round
 constexpr int KL = 20;  // list length up to which the lists' values are mirrored in LDS
@@ -40,11 +41,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int WMB_, int WNB_, int OCC_>
+template <int WMB_, int WNB_, int WVM_, int WVN_, int OCC_>
 struct Cfg {
     static constexpr int WMB = WMB_, WNB = WNB_, OCC = OCC_;  // 32x32 blocks per wave; workgroups per CU
-    static constexpr int BM = 2 * WMB * 32, BN = 2 * WNB * 32;  // 4 waves as 2 x 2
-    static constexpr int A_LD = BM / 32;                      // float4 loads of x per thread and k-step
+    static constexpr int WVM = WVM_, WVN = WVN_, NW = WVM * WVN, NT = 64 * NW;  // waves as WVM x WVN
+    static constexpr int BM = WVM * WMB * 32, BN = WVN * WNB * 32;
+    static constexpr int A_LD = BM * 8 / NT;                  // float4 loads of x per thread and k-step
     static constexpr int B_TPR = BN / 4;                      // threads per W row
     static constexpr int B_RPP = NT / B_TPR;                  // W rows per pass
     static constexpr int B_LD = BK / B_RPP;                   // float4 loads of W per thread and k-step
@@ -52,8 +54,8 @@ struct Cfg {
     static_assert(BN <= 256, "one owner thread per feature, column index packed in 8 bits");
     static_assert(BM <= 256, "row index packed in 8 bits");
 };
-typedef Cfg<2, 2, 2> CfgSmall;
-typedef Cfg<4, 4, 1> CfgLarge;
+typedef Cfg<2, 2, 2, 2, 2> CfgSmall;  // 128x128, 4 waves of 64x64, two workgroups per CU
+typedef Cfg<4, 2, 2, 4, 1> CfgLarge;  // 256x256, 8 waves of 128x64, one workgroup per CU
 
 template <class C, bool DMA, bool LLDS>
 struct __attribute__((aligned(16))) Smem {
@@ -111,18 +113,19 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // both prepared by encode_bf16.hip; a k-step is 64 k (the same 128-byte rows), the W tile is staged exactly
 // like the x tile, and one v_mfma_f32_32x32x16_bf16 replaces four fp32 MFMAs.
 template <class C, int MODE, bool KALIGNED, bool DMA, bool LLDS, bool BF16>
-__global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs a) {
+__global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeArgs a) {
     constexpr int WMB = C::WMB, WNB = C::WNB, BM = C::BM, BN = C::BN;
     constexpr int LDA_ = DMA ? BK : LDA;
     constexpr int ES = BF16 ? 2 : 4;  // bytes per staged element; a k-step is 128 bytes of every row
     static_assert(!BF16 || DMA, "the bf16 operands are staged by LDS-DMA only");
-    constexpr int APW = BM / 32, BPW = BN / 32;  // 1-KiB DMA pieces per wave and k-step (x tile, W tile)
+    constexpr int NT = C::NT;
+    constexpr int APW = BM / 8 / C::NW, BPW = BN / 8 / C::NW;  // 1-KiB DMA pieces per wave and k-step (x tile, W tile)
     static_assert(!DMA || KALIGNED, "DMA staging has no k tail handling");
     static_assert(!LLDS || (DMA && MODE == TSC_MODE_TOPK), "LDS lists belong to the fused top-k DMA kernel");
     __shared__ Smem<C, DMA, LLDS> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int wm0 = (wave >> 1) * (WMB * 32), wn0 = (wave & 1) * (WNB * 32);
+    const int wm0 = (wave / C::WVN) * (WMB * 32), wn0 = (wave % C::WVN) * (WNB * 32);
 
     // Blocks b and b+8 share an XCD (round-robin dispatch): give every XCD its own column tiles
     // so the W_enc slabs of the tiles resident on one XCD stay in that XCD's 4-MiB L2, and the
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
         } else {
 #pragma unroll
             for (int i = 0; i < C::A_LD; ++i) {
-                const int r = a_row + 32 * i < rmax ? a_row + 32 * i : rmax;
+                const int r = a_row + (NT / 8) * i < rmax ? a_row + (NT / 8) * i : rmax;
                 a_voff[i] = (unsigned)(r * a.K + a_col) * 4u;
             }
         }
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(NT, C::OCC) void encode_f32_kernel(const EncodeArgs
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < C::A_LD; ++i)
-            *(f32x4 *)&sm.A[buf][(a_row + 32 * i) * LDA + a_col] = ra[i] - rbd;
+            *(f32x4 *)&sm.A[buf][(a_row + (NT / 8) * i) * LDA + a_col] = ra[i] - rbd;
 #pragma unroll
         for (int i = 0; i < C::B_LD; ++i)
             *(f32x4 *)&sm.B[buf][(b_row + C::B_RPP * i) * BN + b_col] =
@@ -720,32 +723,41 @@ __global__ __launch_bounds__(256) void fold_bias_kernel(const float *__restrict_
     out[n] = (float)((double)b_enc[n] - s);
 }
 
-// Geometry choice: TSC_F32_TILE=128|256 overrides the default (an A/B switch for measurements).
-bool use_large_tile() {
-    static const int choice = [] {
-        const char *e = getenv("TSC_F32_TILE");
-        if (e && atoi(e) == 128) return 0;
-        if (e && atoi(e) == 256) return 1;
-        return TSC_F32_DEFAULT_LARGE;
-    }();
-    return choice != 0;
+// Variant selection.  Each knob is "auto" (0) unless forced, either by an environment variable read once
+// (TSC_F32_TILE / TSC_BF16_TILE = 128|256, TSC_F32_STAGING = reg, TSC_F32_LISTS = hbm) or at run time through
+// tsc_set_tuning (the tests use it to cover every variant in one process).
+struct Tuning {
+    int f32_tile = 0, bf16_tile = 0;  // 0 auto, 128, 256
+    int staging = 0;                  // 0 auto (LDS-DMA when possible), 1 register staging
+    int lists = 0;                    // 0 auto (LDS mirror when possible), 1 lists in HBM only
+    Tuning() {
+        const char *e;
+        if ((e = getenv("TSC_F32_TILE"))) f32_tile = atoi(e);
+        if ((e = getenv("TSC_BF16_TILE"))) bf16_tile = atoi(e);
+        if ((e = getenv("TSC_F32_STAGING")) && e[0] == 'r') staging = 1;
+        if ((e = getenv("TSC_F32_LISTS")) && e[0] == 'h') lists = 1;
+    }
+};
+Tuning &tuning() {
+    static Tuning t;
+    return t;
 }
+bool use_dma() { return tuning().staging == 0; }
+bool use_lds_lists() { return tuning().lists == 0; }
 
-// TSC_F32_STAGING=reg forces register staging (A/B switch; the k-tail kernel always uses it)
-bool use_dma() {
-    static const bool on = [] {
-        const char *e = getenv("TSC_F32_STAGING");
-        return !(e && e[0] == 'r');
-    }();
-    return on;
-}
-
-bool use_lds_lists() {  // TSC_F32_LISTS=hbm: A/B switch
-    static const bool on = [] {
-        const char *e = getenv("TSC_F32_LISTS");
-        return !(e && e[0] == 'h');
-    }();
-    return on;
+// Auto geometry.  256x256 (8 waves, one workgroup per CU) reads each operand byte from L2 half as often and
+// issues fewer non-MFMA instructions per MFMA: it is the faster one for the dense and sparse epilogues and for
+// bf16 (fp32 dense 146 vs 143 TFLOP/s; bf16 top-k 965 vs 915, 1000 vs 760 at d_sae = 131072) as long as its
+// grid still covers the chip.  The fp32 fused top-k keeps 128x128, where the lists' values fit in LDS next
+// to two workgroups per CU (equal speed, no register spills).
+bool pick_large(int mode, const EncodeArgs &a) {
+    const int forced = a.bf16 ? tuning().bf16_tile : tuning().f32_tile;
+    if (forced == 128) return false;
+    if (forced == 256) return true;
+    if (!a.bf16 && mode == TSC_MODE_TOPK) return false;
+    const long long tiles = (long long)((a.N + CfgLarge::BN - 1) / CfgLarge::BN) * ((a.M + CfgLarge::BM - 1) / CfgLarge::BM);
+    if (mode == TSC_MODE_TOPK) return (long long)((a.N + CfgLarge::BN - 1) / CfgLarge::BN) * a.m_split >= 256;
+    return tiles >= 256;
 }
 
 // number of token-tile groups per column tile such that the grid is a whole number of waves of
@@ -768,19 +780,15 @@ int launch(EncodeArgs a, hipStream_t stream) {
     const long long grid = (long long)a.n_tiles_n * a.m_split;
     if (grid <= 0 || grid > 0x7fffffffLL) return tsc_fail(TSC_ERR_ARG, "encode grid %lld out of range", grid);
     const bool dma = a.K % (2 * BK) == 0 && a.bias && a.Wt && use_dma();
-    const dim3 g((unsigned)grid), b(NT);
+    const dim3 g((unsigned)grid), b(C::NT);
     constexpr bool TK = MODE == TSC_MODE_TOPK && C::LDS_LISTS;
     const bool lists = TK && a.topk <= KL && use_lds_lists();
     if (a.bf16) {
         if (a.K % 128 != 0 || !a.bias || !a.Wt) return tsc_fail(TSC_ERR_UNSUPPORTED, "bf16 encode needs d_in %% 128 == 0");
-        if constexpr (C::OCC == 2) {  // the bf16 operands use the 128x128 geometry only
-            if (lists)
-                hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, TK, true>), g, b, 0, stream, a);
-            else
-                hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, false, true>), g, b, 0, stream, a);
-        } else {
-            return tsc_fail(TSC_ERR_UNSUPPORTED, "no bf16 kernel for this tile geometry");
-        }
+        if (lists)
+            hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, TK, true>), g, b, 0, stream, a);
+        else
+            hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, false, true>), g, b, 0, stream, a);
     } else if (dma && lists)
         hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, TK, false>), g, b, 0, stream, a);
     else if (dma)
@@ -826,12 +834,24 @@ int tsc_launch_fold_bias(const float *W, const float *b_enc, const float *b_dec,
 // a.m_split <= 0 asks for the balanced split; a.n_tiles_n is filled in here
 int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream) {
     if (a.M <= 0) return TSC_OK;
-    if (a.bf16) return dispatch<CfgSmall>(mode, a, stream);  // one geometry for the bf16 operands
-    return use_large_tile() ? dispatch<CfgLarge>(mode, a, stream) : dispatch<CfgSmall>(mode, a, stream);
+    return pick_large(mode, a) ? dispatch<CfgLarge>(mode, a, stream) : dispatch<CfgSmall>(mode, a, stream);
 }
 
-int tsc_encode_f32_recommended_slots(int d_sae) {
-    if (use_large_tile())
-        return balanced_split((d_sae + CfgLarge::BN - 1) / CfgLarge::BN, 1 << 30, 256 * CfgLarge::OCC, 16);
+// slot count that makes the fused top-k grid a whole number of waves of resident workgroups
+int tsc_encode_recommended_slots(int d_sae, int bf16) {
+    const int forced = bf16 ? tuning().bf16_tile : tuning().f32_tile;
+    const bool large = forced == 256 || (forced != 128 && bf16);
+    if (large) return balanced_split((d_sae + CfgLarge::BN - 1) / CfgLarge::BN, 1 << 30, 256 * CfgLarge::OCC, 16);
     return balanced_split((d_sae + CfgSmall::BN - 1) / CfgSmall::BN, 1 << 30, 256 * CfgSmall::OCC, 16);
+}
+
+int tsc_encode_set_tuning(const char *key, int value) {
+    Tuning &t = tuning();
+    const std::string k(key ? key : "");
+    if (k == "f32_tile" && (value == 0 || value == 128 || value == 256)) t.f32_tile = value;
+    else if (k == "bf16_tile" && (value == 0 || value == 128 || value == 256)) t.bf16_tile = value;
+    else if (k == "staging" && (value == 0 || value == 1)) t.staging = value;
+    else if (k == "lists" && (value == 0 || value == 1)) t.lists = value;
+    else return tsc_fail(TSC_ERR_ARG, "unknown tuning knob or value: %s = %d", k.c_str(), value);
+    return TSC_OK;
 }

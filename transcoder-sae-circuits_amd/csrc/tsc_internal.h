@@ -47,7 +47,8 @@ struct EncodeArgs {
     int max_active;
 };
 int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream);  // a.m_split <= 0: balanced
-int tsc_encode_f32_recommended_slots(int d_sae);
+int tsc_encode_recommended_slots(int d_sae, int bf16);
+int tsc_encode_set_tuning(const char *key, int value);
 int tsc_launch_fold_bias(const float *W, const float *b_enc, const float *b_dec, int K, int N, float *out,
                          hipStream_t stream);
 int tsc_launch_encode_bf16(int mode, const EncodeArgs &a, const void *W_bf16, void *x_bf16, hipStream_t stream);

@@ -31,6 +31,7 @@ _SIGNATURES = {
     "tsc_dict_destroy": (_c.c_int, [_c.c_void_p]),
     "tsc_encode_dense": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p]),
     "tsc_topk_recommended_slots": (_c.c_int, [_c.c_int]),
+    "tsc_set_tuning": (_c.c_int, [_c.c_char_p, _c.c_int]),
     "tsc_topk_state_reset": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "tsc_encode_topk": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
     "tsc_topk_merge": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
@@ -77,6 +78,11 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+def set_tuning(key: str, value: int) -> None:
+    """Force a kernel variant (tests / measurements): see ``tsc_set_tuning`` in include/tsc_hip.h."""
+    _check(lib().tsc_set_tuning(key.encode(), int(value)))
 
 
 def _check(rc: int) -> None:
