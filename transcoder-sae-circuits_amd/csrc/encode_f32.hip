@@ -50,7 +50,6 @@ struct Cfg {
     static constexpr int B_TPR = BN / 4;                      // threads per W row
     static constexpr int B_RPP = NT / B_TPR;                  // W rows per pass
     static constexpr int B_LD = BK / B_RPP;                   // float4 loads of W per thread and k-step
-    static constexpr bool LDS_LISTS = BN * KL * 4 <= 12 * 1024;  // the mirror must leave room for the staging buffers
     static_assert(BN <= 256, "one owner thread per feature, column index packed in 8 bits");
     static_assert(BM <= 256, "row index packed in 8 bits");
 };
@@ -781,7 +780,8 @@ int launch(EncodeArgs a, hipStream_t stream) {
     if (grid <= 0 || grid > 0x7fffffffLL) return tsc_fail(TSC_ERR_ARG, "encode grid %lld out of range", grid);
     const bool dma = a.K % (2 * BK) == 0 && a.bias && a.Wt && use_dma();
     const dim3 g((unsigned)grid), b(C::NT);
-    constexpr bool TK = MODE == TSC_MODE_TOPK && C::LDS_LISTS;
+    // the mirror of the lists' values must fit in LDS next to the staging buffers of every resident workgroup
+    constexpr bool TK = MODE == TSC_MODE_TOPK && sizeof(Smem<C, true, true>) * C::OCC <= 160 * 1024;
     const bool lists = TK && a.topk <= KL && use_lds_lists();
     if (a.bf16) {
         if (a.K % 128 != 0 || !a.bias || !a.Wt) return tsc_fail(TSC_ERR_UNSUPPORTED, "bf16 encode needs d_in %% 128 == 0");
