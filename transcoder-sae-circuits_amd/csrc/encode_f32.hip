@@ -338,173 +338,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
         }
     };
 
-    // The workgroup's work is one continuous stream of k-steps over all its token tiles: the
-    // prefetch of a tile's first k-step is issued during the previous tile's last one, and the
-    // epilogue runs with the next tile's first k-step already staged.
-    int parity = 0;
-    long long mt = slot;
-    if (mt < n_mtiles) {
-        set_tile(mt * BM);
-        if constexpr (DMA) {
-            const char *xt = (const char *)a.x + (size_t)mt * BM * a.K * ES;
-#pragma unroll
-            for (int j = 0; j < APW + BPW; ++j) dma_piece(j, xt, (const char *)a.Wt, 0, lds_a0, lds_b0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            gload(mt * BM, 0);
-            sstore(0, 0);
-        }
-    }
-    __syncthreads();
-    Frag F, G;
-    if (mt < n_mtiles) ldfrag(0, 0, F);
-
-    for (; mt < n_mtiles; mt += a.m_split) {
-        const long long m0 = mt * BM;
-        f32x16 acc[WMB][WNB];
-#pragma unroll
-        for (int bm = 0; bm < WMB; ++bm)
-#pragma unroll
-            for (int bn = 0; bn < WNB; ++bn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[bm][bn][r] = 0.f;
-
-#define TSC_MFMA_S(FR, s)                                                                        \
-    _Pragma("unroll") for (int bm = 0; bm < WMB; ++bm) _Pragma("unroll") for (int bn = 0; bn < WNB; ++bn) \
-        acc[bm][bn] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR.af[bm][s], FR.bf[bn][s], acc[bm][bn], 0, 0, 0);
-#define TSC_MFMA(FR, S0, S1) _Pragma("unroll") for (int s = S0; s < S1; ++s) { TSC_MFMA_S(FR, s) }
-#define TSC_MFMA_B(FR, bm, bn)                                                                               \
-    acc[bm][bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FR.af[bm]),             \
-                                                          __builtin_bit_cast(bf16x8, FR.bf[bn]), acc[bm][bn], 0, 0, 0);
-#define TSC_MFMA_BALL(FR)                                                                                    \
-    _Pragma("unroll") for (int bm = 0; bm < WMB; ++bm) _Pragma("unroll") for (int bn = 0; bn < WNB; ++bn) { TSC_MFMA_B(FR, bm, bn) }
-
-        // The order inside a k-step is pinned with sched_barrier(0): left alone, hipcc sinks every
-        // fragment read to just before its first use and hoists the barrier above the MFMAs meant
-        // to cover it.
-        if constexpr (DMA) {
-            // Every instruction a wave issues costs the matrix pipe about as much as it would cost
-            // the VALU, so the k-loop is unrolled by two (nk is even: K % 64 == 0): the LDS buffer
-            // is then a compile-time constant, every LDS address an immediate offset, and there is
-            // no per-step branch.  A k-step computes from buffer PAR and fills buffer PAR ^ 1 with
-            // the next k-step -- or, in the tile's last step, with the first k-step of the
-            // workgroup's next tile (of this tile again if there is none: nobody reads that).  The
-            // pieces are issued one per MFMA k-step over the first two groups (an issue burst
-            // would leave the matrix pipe idle) and have the last two groups to land.
-            constexpr int PPS = (APW + BPW) / 8;
-            const bool has_next = mt + a.m_split < n_mtiles;
-            const long long next_m0 = has_next ? (mt + a.m_split) * BM : m0;
-            const char *xt = (const char *)a.x + (size_t)m0 * a.K * ES + 128;  // k-step 1 of this tile
-            const char *wt = (const char *)a.Wt + 128;
-            auto kstep = [&](auto par_) {
-                constexpr int PAR = decltype(par_)::value;
-                // keep the tile bases in scalar registers (saddr + 32-bit lane offset addressing);
-                // otherwise loop strength reduction turns every piece's address into a 64-bit
-                // vector induction variable
-                const char *xp = xt, *wp = wt;
-                // likewise the piece destinations: one base plus an immediate each, not 16 hoisted constants
-                unsigned la = lds_a0, lb = lds_b0;
-                asm volatile("" : "+s"(xp), "+s"(wp), "+s"(la), "+s"(lb));
-#pragma unroll
-                for (int j = 0; j < BPW; ++j) asm volatile("" : "+v"(b_voff[j]));  // same, for the hoisted zero-extensions
-#pragma unroll
-                for (int j = 0; j < APW; ++j) asm volatile("" : "+v"(a_voff[j]));
-                if constexpr (BF16) {
-                    // 4 MFMAs (32 cycles each) per 16-k group: the pieces go out two per MFMA in the
-                    // first group and have the other three to land
-                    constexpr int PPM = (APW + BPW) / (WMB * WNB);
-                    TSC_PIN ldfrag(PAR, 1, G);
-#pragma unroll
-                    for (int bm = 0; bm < WMB; ++bm)
-#pragma unroll
-                        for (int bn = 0; bn < WNB; ++bn) {
-                            TSC_PIN
-#pragma unroll
-                            for (int jj = 0; jj < PPM; ++jj) dma_piece((bm * WNB + bn) * PPM + jj, xp, wp, PAR ^ 1, la, lb);
-                            TSC_PIN TSC_MFMA_B(F, bm, bn)
-                        }
-                    TSC_PIN ldfrag(PAR, 2, F);
-                    TSC_PIN TSC_MFMA_BALL(G)
-                    TSC_PIN ldfrag(PAR, 3, G);
-                    TSC_PIN TSC_MFMA_BALL(F)
-                    TSC_PIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    TSC_PIN ldfrag(PAR ^ 1, 0, F);
-                    TSC_PIN TSC_MFMA_BALL(G)
-                    TSC_PIN
-                } else {
-                    TSC_PIN ldfrag(PAR, 1, G);
-    #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        TSC_PIN
-    #pragma unroll
-                        for (int jj = 0; jj < PPS; ++jj) dma_piece(s * PPS + jj, xp, wp, PAR ^ 1, la, lb);
-                        TSC_PIN TSC_MFMA_S(F, s)
-                    }
-                    TSC_PIN ldfrag(PAR, 2, F);
-    #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        TSC_PIN
-    #pragma unroll
-                        for (int jj = 0; jj < PPS; ++jj) dma_piece((4 + s) * PPS + jj, xp, wp, PAR ^ 1, la, lb);
-                        TSC_PIN TSC_MFMA_S(G, s)
-                    }
-                    TSC_PIN ldfrag(PAR, 3, G);
-                    TSC_PIN TSC_MFMA(F, 0, 4)
-                    TSC_PIN TSC_MFMA(G, 0, 2)
-                    TSC_PIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed
-                    __syncthreads();
-                    TSC_PIN ldfrag(PAR ^ 1, 0, F);
-                    TSC_PIN TSC_MFMA(G, 2, 4)
-                    TSC_PIN
-                }
-            };
-            for (int kt = 0; kt < nk; kt += 2) {
-                kstep(std::integral_constant<int, 0>());
-                if (kt + 2 == nk) {
-                    set_tile(next_m0);
-                    xt = (const char *)a.x + (size_t)next_m0 * a.K * ES;
-                    wt = (const char *)a.Wt;
-                } else {
-                    xt += 128;
-                    wt += 128;
-                }
-                kstep(std::integral_constant<int, 1>());
-                xt += 128;
-                wt += 128;
-            }
-        } else {
-            for (int kt = 0; kt < nk; ++kt) {
-                // what to prefetch: the next k-step of this tile, or the first of the next tile
-                const bool last_k = kt + 1 == nk;
-                const long long next_m0 = last_k ? (mt + a.m_split) * BM : m0;
-                const int next_k0 = last_k ? 0 : (kt + 1) * BK;
-                const bool more = !last_k || mt + a.m_split < n_mtiles;
-                if (last_k && more) set_tile(next_m0);
-                if (more) gload(next_m0, next_k0);
-                TSC_PIN ldfrag(parity, 1, G);
-                TSC_PIN TSC_MFMA(F, 0, 4)
-                TSC_PIN ldfrag(parity, 2, F);
-                TSC_PIN TSC_MFMA(G, 0, 4)
-                TSC_PIN ldfrag(parity, 3, G);
-                TSC_PIN TSC_MFMA(F, 0, 4)
-                // stage the prefetched k-step into the other buffer (free since the last barrier),
-                // cover the LDS write latency and the barrier with the first half of the last group,
-                // and the first fragment read of the new buffer with the second half
-                TSC_PIN if (more) sstore(parity ^ 1, next_k0);
-                TSC_PIN TSC_MFMA(G, 0, 2)
-                TSC_PIN __syncthreads();
-                TSC_PIN if (more) ldfrag(parity ^ 1, 0, F);
-                TSC_PIN TSC_MFMA(G, 2, 4)
-                TSC_PIN
-                parity ^= 1;
-            }
-        }
-#undef TSC_MFMA_S
-#undef TSC_MFMA_B
-#undef TSC_MFMA_BALL
-#undef TSC_MFMA
-
+    auto epilogue = [&](f32x16 (&acc)[WMB][WNB], const long long m0) {
         // ---------------------------------------------------------------- epilogues
         // C layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
         // The lane's row/column bases are made opaque once per tile: otherwise hipcc hoists the
@@ -701,6 +535,177 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
             }
         }
 #undef TSC_FOR_ACC
+    };
+
+#define TSC_MFMA_S(FR, s)                                                                        \
+    _Pragma("unroll") for (int bm = 0; bm < WMB; ++bm) _Pragma("unroll") for (int bn = 0; bn < WNB; ++bn) \
+        acc[bm][bn] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR.af[bm][s], FR.bf[bn][s], acc[bm][bn], 0, 0, 0);
+#define TSC_MFMA(FR, S0, S1) _Pragma("unroll") for (int s = S0; s < S1; ++s) { TSC_MFMA_S(FR, s) }
+#define TSC_MFMA_B(FR, bm, bn)                                                                               \
+    acc[bm][bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FR.af[bm]),             \
+                                                          __builtin_bit_cast(bf16x8, FR.bf[bn]), acc[bm][bn], 0, 0, 0);
+#define TSC_MFMA_BALL(FR)                                                                                    \
+    _Pragma("unroll") for (int bm = 0; bm < WMB; ++bm) _Pragma("unroll") for (int bn = 0; bn < WNB; ++bn) { TSC_MFMA_B(FR, bm, bn) }
+
+
+    // The workgroup's work is one continuous stream of k-steps over all its token tiles: the
+    // prefetch of a tile's first k-step is issued during the previous tile's last one, and the
+    // epilogue runs with the next tile's first k-step already staged.
+    int parity = 0;
+    long long mt = slot;
+    if (mt < n_mtiles) {
+        set_tile(mt * BM);
+        if constexpr (DMA) {
+            const char *xt = (const char *)a.x + (size_t)mt * BM * a.K * ES;
+#pragma unroll
+            for (int j = 0; j < APW + BPW; ++j) dma_piece(j, xt, (const char *)a.Wt, 0, lds_a0, lds_b0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            gload(mt * BM, 0);
+            sstore(0, 0);
+        }
+    }
+    __syncthreads();
+    Frag F, G;
+    if (mt < n_mtiles) ldfrag(0, 0, F);
+
+    for (; mt < n_mtiles; mt += a.m_split) {
+        const long long m0 = mt * BM;
+        f32x16 acc[WMB][WNB];
+#pragma unroll
+        for (int bm = 0; bm < WMB; ++bm)
+#pragma unroll
+            for (int bn = 0; bn < WNB; ++bn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[bm][bn][r] = 0.f;
+
+        // The order inside a k-step is pinned with sched_barrier(0): left alone, hipcc sinks every
+        // fragment read to just before its first use and hoists the barrier above the MFMAs meant
+        // to cover it.
+        if constexpr (DMA) {
+            // Every instruction a wave issues costs the matrix pipe about as much as it would cost
+            // the VALU, so the k-loop is unrolled by two (nk is even: K % 64 == 0): the LDS buffer
+            // is then a compile-time constant, every LDS address an immediate offset, and there is
+            // no per-step branch.  A k-step computes from buffer PAR and fills buffer PAR ^ 1 with
+            // the next k-step -- or, in the tile's last step, with the first k-step of the
+            // workgroup's next tile (of this tile again if there is none: nobody reads that).  The
+            // pieces are issued one per MFMA k-step over the first two groups (an issue burst
+            // would leave the matrix pipe idle) and have the last two groups to land.
+            constexpr int PPS = (APW + BPW) / 8;
+            const bool has_next = mt + a.m_split < n_mtiles;
+            const long long next_m0 = has_next ? (mt + a.m_split) * BM : m0;
+            const char *xt = (const char *)a.x + (size_t)m0 * a.K * ES + 128;  // k-step 1 of this tile
+            const char *wt = (const char *)a.Wt + 128;
+            auto kstep = [&](auto par_) {
+                constexpr int PAR = decltype(par_)::value;
+                // keep the tile bases in scalar registers (saddr + 32-bit lane offset addressing);
+                // otherwise loop strength reduction turns every piece's address into a 64-bit
+                // vector induction variable
+                const char *xp = xt, *wp = wt;
+                // likewise the piece destinations: one base plus an immediate each, not 16 hoisted constants
+                unsigned la = lds_a0, lb = lds_b0;
+                asm volatile("" : "+s"(xp), "+s"(wp), "+s"(la), "+s"(lb));
+#pragma unroll
+                for (int j = 0; j < BPW; ++j) asm volatile("" : "+v"(b_voff[j]));  // same, for the hoisted zero-extensions
+#pragma unroll
+                for (int j = 0; j < APW; ++j) asm volatile("" : "+v"(a_voff[j]));
+                if constexpr (BF16) {
+                    // 4 MFMAs (32 cycles each) per 16-k group: the pieces go out two per MFMA in the
+                    // first group and have the other three to land
+                    constexpr int PPM = (APW + BPW) / (WMB * WNB);
+                    TSC_PIN ldfrag(PAR, 1, G);
+#pragma unroll
+                    for (int bm = 0; bm < WMB; ++bm)
+#pragma unroll
+                        for (int bn = 0; bn < WNB; ++bn) {
+                            TSC_PIN
+#pragma unroll
+                            for (int jj = 0; jj < PPM; ++jj) dma_piece((bm * WNB + bn) * PPM + jj, xp, wp, PAR ^ 1, la, lb);
+                            TSC_PIN TSC_MFMA_B(F, bm, bn)
+                        }
+                    TSC_PIN ldfrag(PAR, 2, F);
+                    TSC_PIN TSC_MFMA_BALL(G)
+                    TSC_PIN ldfrag(PAR, 3, G);
+                    TSC_PIN TSC_MFMA_BALL(F)
+                    TSC_PIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    TSC_PIN ldfrag(PAR ^ 1, 0, F);
+                    TSC_PIN TSC_MFMA_BALL(G)
+                    TSC_PIN
+                } else {
+                    TSC_PIN ldfrag(PAR, 1, G);
+    #pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        TSC_PIN
+    #pragma unroll
+                        for (int jj = 0; jj < PPS; ++jj) dma_piece(s * PPS + jj, xp, wp, PAR ^ 1, la, lb);
+                        TSC_PIN TSC_MFMA_S(F, s)
+                    }
+                    TSC_PIN ldfrag(PAR, 2, F);
+    #pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        TSC_PIN
+    #pragma unroll
+                        for (int jj = 0; jj < PPS; ++jj) dma_piece((4 + s) * PPS + jj, xp, wp, PAR ^ 1, la, lb);
+                        TSC_PIN TSC_MFMA_S(G, s)
+                    }
+                    TSC_PIN ldfrag(PAR, 3, G);
+                    TSC_PIN TSC_MFMA(F, 0, 4)
+                    TSC_PIN TSC_MFMA(G, 0, 2)
+                    TSC_PIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed
+                    __syncthreads();
+                    TSC_PIN ldfrag(PAR ^ 1, 0, F);
+                    TSC_PIN TSC_MFMA(G, 2, 4)
+                    TSC_PIN
+                }
+            };
+            for (int kt = 0; kt < nk; kt += 2) {
+                kstep(std::integral_constant<int, 0>());
+                if (kt + 2 == nk) {
+                    set_tile(next_m0);
+                    xt = (const char *)a.x + (size_t)next_m0 * a.K * ES;
+                    wt = (const char *)a.Wt;
+                } else {
+                    xt += 128;
+                    wt += 128;
+                }
+                kstep(std::integral_constant<int, 1>());
+                xt += 128;
+                wt += 128;
+            }
+        } else {
+            for (int kt = 0; kt < nk; ++kt) {
+                // what to prefetch: the next k-step of this tile, or the first of the next tile
+                const bool last_k = kt + 1 == nk;
+                const long long next_m0 = last_k ? (mt + a.m_split) * BM : m0;
+                const int next_k0 = last_k ? 0 : (kt + 1) * BK;
+                const bool more = !last_k || mt + a.m_split < n_mtiles;
+                if (last_k && more) set_tile(next_m0);
+                if (more) gload(next_m0, next_k0);
+                TSC_PIN ldfrag(parity, 1, G);
+                TSC_PIN TSC_MFMA(F, 0, 4)
+                TSC_PIN ldfrag(parity, 2, F);
+                TSC_PIN TSC_MFMA(G, 0, 4)
+                TSC_PIN ldfrag(parity, 3, G);
+                TSC_PIN TSC_MFMA(F, 0, 4)
+                // stage the prefetched k-step into the other buffer (free since the last barrier),
+                // cover the LDS write latency and the barrier with the first half of the last group,
+                // and the first fragment read of the new buffer with the second half
+                TSC_PIN if (more) sstore(parity ^ 1, next_k0);
+                TSC_PIN TSC_MFMA(G, 0, 2)
+                TSC_PIN __syncthreads();
+                TSC_PIN if (more) ldfrag(parity ^ 1, 0, F);
+                TSC_PIN TSC_MFMA(G, 2, 4)
+                TSC_PIN
+                parity ^= 1;
+            }
+        }
+#undef TSC_MFMA_S
+#undef TSC_MFMA_B
+#undef TSC_MFMA_BALL
+#undef TSC_MFMA
+
+        epilogue(acc, m0);
     }
 #ifdef TSC_STAMPS
     if (MODE == TSC_MODE_TOPK && (tid == 0 || tid == 192)) {
