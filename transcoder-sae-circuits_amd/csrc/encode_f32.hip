@@ -1,29 +1,33 @@
-// Dictionary encode on the gfx950 fp32 matrix pipe, with three epilogues.
+// Dictionary encode on the gfx950 matrix pipe (fp32, or bf16 operands), with three epilogues.
 //
 //   acts[m, n] = relu( sum_k (x[m,k] - b_dec[k]) * W_enc[k,n] + b_enc[n] )
 //
 // replaces SparseTranscoder.encode (reference src/mlp_transcoder.py:194-213) and ZSAE.encode
-// (src/z_sae.py:73-77).  One workgroup (4 waves, one per SIMD) owns one column tile of the
-// dictionary and walks a strided set of token row tiles, so the per-feature state of the fused top-k
-// epilogue stays with that workgroup for the whole launch.
+// (src/z_sae.py:73-77).  One workgroup owns one column tile of the dictionary and walks a strided set of
+// token row tiles, so the per-feature state of the fused top-k epilogue stays with that workgroup for the
+// whole launch.  DESIGN.md section 4.1 has the measurements behind every choice below.
 //
-//   main loop : K in steps of 32; x and W_enc tiles prefetched global->VGPR during the MFMAs of the
-//               previous step, written to a double-buffered LDS image after them (one barrier per
-//               step); `x - b_dec` is applied while staging (the reference subtracts before the
-//               contraction, mlp_transcoder.py:200-202).  Each wave computes WMB x WNB
-//               v_mfma_f32_32x32x2_f32 accumulators: exact fp32, one rounding per product.
-//   DENSE     : + b_enc, ReLU, streaming store of the [M, d_sae] matrix.
-//   TOPK      : + b_enc, compare against the feature's current k-th best; survivors go through an
-//               LDS queue to the thread that owns the feature, which updates the feature's list
-//               in HBM.  The activation matrix is never written.  (max_act_analysis.py:232-249 for
-//               all features at once.)
-//   SPARSE    : + b_enc, every activation > 0 is appended to its token's (feature, value) list
+//   main loop : LDS-DMA variant (d_in % 64 == 0): the raw x tile and the tile of the handle's transposed
+//               W_enc copy go global -> LDS by global_load_lds_dwordx4 (8 rows x 128 bytes per piece,
+//               16-byte chunks XOR-swizzled through the source address), two LDS buffers, one barrier per
+//               k-step, k-loop unrolled by two so that every LDS address is an immediate; b_dec is folded
+//               into the bias (bias' = b_enc - b_dec @ W_enc).  Register-staged variant (any d_in % 4 == 0):
+//               tiles prefetched global -> VGPR, `x - b_dec` applied while they are written to LDS, as the
+//               reference subtracts before the contraction (mlp_transcoder.py:200-202).
+//               fp32: v_mfma_f32_32x32x2_f32, exact fp32, one rounding per product.
+//               bf16: v_mfma_f32_32x32x16_bf16 on operands prepared by encode_operands.hip.
+//   DENSE     : + bias, ReLU, streaming store of the [M, d_sae] matrix.
+//   TOPK      : + bias, compare against the feature's current k-th best (its own slot's, and the cross-slot
+//               floor); survivors go through per-feature LDS slots to the thread that owns the feature,
+//               which updates the feature's list (values mirrored in LDS, HBM written through).  The
+//               activation matrix is never written.  (max_act_analysis.py:232-249 for all features at once.)
+//   SPARSE    : + bias, every activation > 0 is appended to its token's (feature, value) list
 //               (circuit_lens.py:612-614 / 647-649 before the sort).
 //
-// Two tile geometries are compiled (Cfg): 128x128 per workgroup with two workgroups per CU, and
-// 256x256 with one workgroup per CU holding 256 accumulator registers per lane.  On this pipe the
-// VALU shares the SIMD's issue with the fp32 MFMA and a wave issues in order, so what decides the
-// rate is the number of non-MFMA instructions per MFMA; the large tile halves it.
+// Two tile geometries are compiled (Cfg): 128x128 (4 waves, two workgroups per CU) and 256x256 (8 waves,
+// one workgroup per CU); pick_large() chooses per call.  On this pipe every instruction a wave issues costs
+// the matrix pipe about as much as it would cost the VALU, so the design rule throughout is: as few
+// non-MFMA instructions per MFMA as possible.
 #include <cstdlib>
 #include <string>
 #include <type_traits>
