@@ -140,16 +140,13 @@ def main():
     def finish():
         outs = [st.finalize() for st in states]
         if world > 1:
-            from topk_scan import allgather_merge
+            from topk_scan import allgather_merge_many
 
-            merged = []
-            for vals, idx in outs:
-                if args.rehearse_on_one_gpu:  # gloo moves host tensors; the merge still runs on the device
-                    merged.append(allgather_merge(vals.cpu(), idx.cpu(),
-                                                  lambda v, i: tsc_hip.topk_merge(v.to(device), i.to(device))))
-                else:
-                    merged.append(allgather_merge(vals, idx, tsc_hip.topk_merge))
-            outs = merged
+            if args.rehearse_on_one_gpu:  # gloo moves host tensors; the merge still runs on the device
+                outs = allgather_merge_many([(v.cpu(), i.cpu()) for v, i in outs],
+                                            lambda v, i: tsc_hip.topk_merge(v.to(device), i.to(device)))
+            else:
+                outs = allgather_merge_many(outs, tsc_hip.topk_merge)
         return outs
 
     def barrier():

@@ -64,6 +64,17 @@ def allgather_merge(vals: torch.Tensor, idx: torch.Tensor, merge: Callable, grou
     return merge(gv.view(world, d_sae, k), gi.view(world, d_sae, k))
 
 
+def allgather_merge_many(lists, merge: Callable, group=None):
+    """:func:`allgather_merge` for several dictionaries at once: their finalized lists (same ``k``) are
+    concatenated along the feature axis, so the whole exchange is two all-gathers and one merge launch
+    whatever the number of dictionaries (the merge treats the concatenation as one wide dictionary)."""
+    widths = [v.shape[0] for v, _ in lists]
+    vals = torch.cat([v for v, _ in lists], dim=0)
+    idx = torch.cat([i for _, i in lists], dim=0)
+    mv, mi = allgather_merge(vals, idx, merge, group)
+    return list(zip(torch.split(mv, widths, dim=0), torch.split(mi, widths, dim=0)))
+
+
 class MaxActSweep:
     """Top-k lists for a set of named dictionaries fed with activation batches.
 
@@ -95,13 +106,11 @@ class MaxActSweep:
         self.tokens_seen += n or 0
 
     def result(self) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
-        out = {}
-        for name, eng in self.engines.items():
-            vals, idx = eng.finalize()
-            if self.distributed:
-                vals, idx = allgather_merge(vals, idx, eng.merge, self.group)
-            out[name] = (vals, idx)
-        return out
+        names = list(self.engines)
+        lists = [self.engines[n].finalize() for n in names]
+        if self.distributed and names:
+            lists = allgather_merge_many(lists, self.engines[names[0]].merge, self.group)
+        return dict(zip(names, lists))
 
 
 def hook_names(kind: str, layer: int, encoder=None) -> str:
