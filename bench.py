@@ -82,8 +82,8 @@ def cpu_baseline(tokens, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--tokens-per-step", type=int, default=16384)  # 128 seqs x 128 pos, max_act_analysis.py:25
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--cpu-tokens", type=int, default=65536)
