@@ -82,15 +82,19 @@ int tsc_encode_dense(const tsc_dict_t *dict, const float *x, int64_t M, float *o
  * floor (optional, may be NULL): [d_sae] fp32 scratch.  When given and n_slots > 1, tsc_encode_topk first
  * writes each feature's current k-th best value over ALL slots into it and the encode kernel dismisses
  * candidates below it -- they cannot be in the merged result -- instead of only those below the k-th best
- * of their own slot (n_slots times fewer list updates).  Its contents carry nothing between calls.
+ * of their own slot (n_slots times fewer list updates).  A floor stays a valid (if weaker) bound for as long
+ * as the lists only grow, so a caller may skip the recomputation on some calls: flags bit 0
+ * (TSC_TOPK_FLOOR_KEEP) = "floor still holds what an earlier tsc_encode_topk on this state wrote and the lists
+ * were not reset or replaced since: use it as it is".
  */
+#define TSC_TOPK_FLOOR_KEEP 1
 typedef struct {
     float *vals;   /* device */
     int64_t *idx;  /* device */
     int32_t d_sae;
     int32_t k;       /* 1..64 */
     int32_t n_slots; /* 1..64 */
-    int32_t reserved;
+    int32_t flags;   /* TSC_TOPK_FLOOR_KEEP or 0 */
     float *floor;  /* device, [d_sae] scratch, or NULL */
 } tsc_topk_state_t;
 

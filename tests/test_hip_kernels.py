@@ -332,6 +332,32 @@ def test_bf16_wide_dictionary_config5_shape():
         assert int((~same).sum()) <= same.numel() // 200
 
 
+def test_fused_topk_many_calls_with_kept_floor():
+    """More calls than the floor warm-up: most of them reuse an older cross-slot floor
+    (TSC_TOPK_FLOOR_KEEP); the result must still be the exact ranking, also after a resume."""
+    import tsc_hip
+
+    g, w, xs, n_seq, n_pos = gi.g2_inputs()
+    d, _ = _dd(w)
+    x = torch.cat([xs, xs.flip(0) * 1.01, xs[::2] * 0.99])
+    xg = x.to(DEV)
+    exp_v, exp_i = _rank_own_dense(d.encode_dense(xg), 20)
+    st = tsc_hip.TopkState(1536, 20, DEV, n_slots=4)
+    batch = 256  # 40 calls
+    half = (xg.shape[0] // 2 // batch) * batch
+    for s in range(0, half, batch):
+        d.encode_topk(xg[s:s + batch], s, st)
+    assert st._calls > st.FLOOR_WARM_CALLS and st._struct.flags in (0, 1)
+    v, i = st.finalize()
+    st2 = tsc_hip.TopkState(1536, 20, DEV, n_slots=4)
+    st2.load(v, i)  # resume: the floor starts over
+    assert st2._calls == 0
+    for s in range(half, xg.shape[0], batch):
+        d.encode_topk(xg[s:s + batch], s, st2)
+    v, i = st2.finalize()
+    assert torch.equal(v.cpu(), exp_v) and torch.equal(i.cpu(), exp_i)
+
+
 def test_topk_merge_and_resume():
     import tsc_hip
 

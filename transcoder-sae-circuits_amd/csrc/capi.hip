@@ -170,8 +170,10 @@ int tsc_encode_topk(const tsc_dict_t *d, const float *x, int64_t M, int64_t toke
     a.token_base = token_id_base;
     a.m_split = s->n_slots;
     if (s->floor && s->n_slots > 1) {
-        rc = tsc_launch_topk_floor(s->vals, s->n_slots, s->d_sae, s->k, s->floor, (hipStream_t)stream);
-        if (rc) return rc;
+        if (!(s->flags & TSC_TOPK_FLOOR_KEEP)) {
+            rc = tsc_launch_topk_floor(s->vals, s->n_slots, s->d_sae, s->k, s->floor, (hipStream_t)stream);
+            if (rc) return rc;
+        }
         a.tk_floor = s->floor;
     }
     return run_encode(d, TSC_MODE_TOPK, a, (hipStream_t)stream);

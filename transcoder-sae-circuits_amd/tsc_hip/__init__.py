@@ -56,7 +56,7 @@ class TscError(RuntimeError):
 
 class _TopkStateStruct(ctypes.Structure):
     _fields_ = [("vals", _c.c_void_p), ("idx", _c.c_void_p), ("d_sae", _c.c_int32), ("k", _c.c_int32),
-                ("n_slots", _c.c_int32), ("reserved", _c.c_int32), ("floor", _c.c_void_p)]
+                ("n_slots", _c.c_int32), ("flags", _c.c_int32), ("floor", _c.c_void_p)]
 
 
 def library_path() -> str:
@@ -171,6 +171,7 @@ class DeviceDict:
     # ------------------------------------------------------------------ top-k
     def encode_topk(self, x: torch.Tensor, token_id_base: int, state: "TopkState") -> None:
         x2 = _dev(x, torch.float32, "x").reshape(-1, self.d_in)
+        state._schedule_floor()
         with torch.cuda.device(x.device):
             _check(lib().tsc_encode_topk(self._handle, x2.data_ptr(), x2.shape[0], int(token_id_base),
                                          ctypes.byref(state._struct), _stream()))
@@ -243,13 +244,27 @@ class TopkState:
         self.idx = torch.empty(self.n_slots, d_sae, k, dtype=torch.int64, device=self.device)
         # scratch for the k-th best over all slots (see include/tsc_hip.h); not part of the state's content
         self.floor = torch.zeros(d_sae, dtype=torch.float32, device=self.device) if cross_slot_floor else None
+        self._calls = 0
         self._struct = _TopkStateStruct(self.vals.data_ptr(), self.idx.data_ptr(), d_sae, k, self.n_slots, 0,
                                         self.floor.data_ptr() if cross_slot_floor else None)
         self.reset()
 
+    FLOOR_EVERY = 4      # once the lists are warm the cross-slot floor is recomputed on every 4th call only:
+    FLOOR_WARM_CALLS = 8  # an older floor is still a valid bound (include/tsc_hip.h, TSC_TOPK_FLOOR_KEEP)
+
     def reset(self) -> None:
         with torch.cuda.device(self.device):
             _check(lib().tsc_topk_state_reset(ctypes.byref(self._struct), _stream()))
+        self.invalidate_floor()
+
+    def invalidate_floor(self) -> None:
+        """Call after writing ``vals`` / ``idx`` directly: the next encode recomputes the floor."""
+        self._calls = 0
+
+    def _schedule_floor(self) -> None:
+        keep = self._calls >= self.FLOOR_WARM_CALLS and self._calls % self.FLOOR_EVERY != 0
+        self._struct.flags = 1 if keep else 0
+        self._calls += 1
 
     def finalize(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """Merged, sorted ``(vals [d_sae,k], idx [d_sae,k])``; the state stays usable."""
@@ -264,6 +279,7 @@ class TopkState:
         self.reset()
         self.vals[0].copy_(vals)
         self.idx[0].copy_(idx)
+        self.invalidate_floor()
 
 
 def topk_merge(vals: torch.Tensor, idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
