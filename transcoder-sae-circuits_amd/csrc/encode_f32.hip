@@ -787,13 +787,16 @@ int launch(EncodeArgs a, hipStream_t stream) {
         a.m_split = balanced_split(a.n_tiles_n, (a.M + C::BM - 1) / C::BM, 256 * C::OCC, 64);
     const long long grid = (long long)a.n_tiles_n * a.m_split;
     if (grid <= 0 || grid > 0x7fffffffLL) return tsc_fail(TSC_ERR_ARG, "encode grid %lld out of range", grid);
-    const bool dma = a.K % (2 * BK) == 0 && a.bias && a.Wt && use_dma();
+    // the LDS-DMA kernels address the transposed operand with 32-bit lane offsets
+    const bool fits32 = (unsigned long long)a.N * a.K * (a.bf16 ? 2 : 4) + 8192ull < (1ull << 32);
+    const bool dma = a.K % (2 * BK) == 0 && a.bias && a.Wt && fits32 && use_dma();
     const dim3 g((unsigned)grid), b(C::NT);
     // the mirror of the lists' values must fit in LDS next to the staging buffers of every resident workgroup
     constexpr bool TK = MODE == TSC_MODE_TOPK && sizeof(Smem<C, true, true>) * C::OCC <= 160 * 1024;
     const bool lists = TK && a.topk <= KL && use_lds_lists();
     if (a.bf16) {
         if (a.K % 128 != 0 || !a.bias || !a.Wt) return tsc_fail(TSC_ERR_UNSUPPORTED, "bf16 encode needs d_in %% 128 == 0");
+        if (!fits32) return tsc_fail(TSC_ERR_UNSUPPORTED, "bf16 encode needs d_in * d_sae * 2 < 4 GiB");
         if (lists)
             hipLaunchKernelGGL((encode_f32_kernel<C, MODE, true, true, TK, true>), g, b, 0, stream, a);
         else
