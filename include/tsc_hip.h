@@ -71,6 +71,14 @@ int tsc_dict_destroy(tsc_dict_t *dict);
  */
 int tsc_encode_dense(const tsc_dict_t *dict, const float *x, int64_t M, float *out,
                      tsc_stream_t stream);
+/*
+ * out[M,d_sae] = (x - b_dec) @ W_enc + b_enc, the pre-activation: what the reference exposes as
+ * hook_hidden_pre (mlp_transcoder.py:204-211) and what get_feature_scores' raw mode computes for selected
+ * columns (autointerpretability.py:226-238).  A handle made from a few selected encoder columns turns that
+ * column selection into a skinny MFMA GEMM (tsc_hip.FeatureProjector).
+ */
+int tsc_encode_dense_pre(const tsc_dict_t *dict, const float *x, int64_t M, float *out,
+                         tsc_stream_t stream);
 
 /*
  * Running per-feature top-k of max-activating tokens.  The state is caller-owned device memory:

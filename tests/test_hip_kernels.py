@@ -358,6 +358,26 @@ def test_fused_topk_many_calls_with_kept_floor():
     assert torch.equal(v.cpu(), exp_v) and torch.equal(i.cpu(), exp_i)
 
 
+@pytest.mark.parametrize("n_feat", [1, 5, 7, 64, 70])
+def test_feature_projector_matches_oracle(n_feat):
+    """Selected encoder columns over a long token stream: the skinny-GEMM route (>= 6 columns, padded to a
+    multiple of 4) and the per-row kernel must both give raw_feature_scores_ref (autointerpretability.py:
+    226-238) and, with the ReLU, the columns of the full encode."""
+    import tsc_hip
+
+    g, w, xs, n_seq, n_pos = gi.g2_inputs()
+    feats = torch.arange(3, 3 + 19 * n_feat, 19) % 1536
+    Pt = w["W_enc"][:, feats].t().contiguous().to(DEV)
+    bias = w["b_enc"][feats].contiguous().to(DEV)
+    proj = tsc_hip.FeatureProjector(Pt, bias, w["b_dec"].to(DEV))
+    x = xs[:3000]
+    raw = E.raw_feature_scores_ref(x, w, feats)
+    for rows in (3000, 100):  # long input: GEMM route when eligible; short: per-row kernel
+        _close(proj(x[:rows].to(DEV), relu=False), raw[:rows])
+        _close(proj(x[:rows].to(DEV), relu=True), torch.clamp_min(raw[:rows], 0))
+    proj.close()
+
+
 def test_topk_merge_and_resume():
     import tsc_hip
 

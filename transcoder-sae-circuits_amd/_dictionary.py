@@ -75,7 +75,20 @@ class HipDictionaryMixin:
         self._require_gpu_fp32()
         x = x.to(device=self.W_enc.device, dtype=torch.float32).contiguous()
         feats = torch.as_tensor(features, device=self.W_enc.device, dtype=torch.long).reshape(-1)
-        Pt = self.W_enc.data.index_select(1, feats).t().contiguous()
-        bias = self.b_enc.data.index_select(0, feats).contiguous()
-        out = tsc_hip.project_features(x, Pt, bias, self.b_dec.data.contiguous(), relu=relu)
+        out = self.feature_projector(feats)(x, relu=relu)
         return out.reshape(*x.shape[:-1], feats.numel())
+
+    def feature_projector(self, feats: torch.Tensor) -> "tsc_hip.FeatureProjector":
+        """Projector onto the selected encoder columns, cached per feature list for as long as the
+        parameters keep their storage and values (callers loop over batches with one feature list)."""
+        params = (self.W_enc, self.b_enc, self.b_dec)
+        key = (tuple(feats.tolist()), tuple(p.data_ptr() for p in params), tuple(p._version for p in params))
+        cache = self.__dict__.setdefault("_projectors", {})
+        proj = cache.get(key)
+        if proj is None:
+            while len(cache) >= 4:  # a handful of feature lists is all a sweep uses at a time
+                cache.pop(next(iter(cache))).close()
+            Pt = self.W_enc.detach().index_select(1, feats).t().contiguous()
+            bias = self.b_enc.detach().index_select(0, feats).contiguous()
+            proj = cache[key] = tsc_hip.FeatureProjector(Pt, bias, self.b_dec.detach().contiguous())
+        return proj

@@ -34,6 +34,14 @@ def get_feature_scores(model, encoder, tokens_arr, feature_indices, batch_size=6
     feats = torch.as_tensor(feature_indices, dtype=torch.long, device=encoder.W_enc.device).reshape(-1)
     eos = model.tokenizer.eos_token  # a *string*: the reference's comparison with int tokens (:244-247) never matches
     scores = []
+    post_projector = None
+    if use_raw_scores and feature_post is not None:
+        post = feature_post.to(encoder.W_enc.device, torch.float32)
+        if isinstance(encoder, SparseTranscoder) and use_decoder:
+            bias = -(encoder.b_dec @ post)
+        else:
+            bias = encoder.b_enc[feats] - (encoder.b_dec @ post)
+        post_projector = tsc_hip.FeatureProjector(post.t().contiguous(), bias.detach().contiguous(), None)
     for i in range(0, tokens_arr.shape[0], batch_size):
         cur_tokens = tokens_arr[i: i + batch_size]
         with torch.no_grad():
@@ -43,12 +51,7 @@ def get_feature_scores(model, encoder, tokens_arr, feature_indices, batch_size=6
                 if feature_post is None:
                     cur = encoder.encode_features(acts, feats, relu=False)  # :226-238 (pre-ReLU, bias folded)
                 else:
-                    post = feature_post.to(acts.device, torch.float32)
-                    if isinstance(encoder, SparseTranscoder) and use_decoder:
-                        bias = -(encoder.b_dec @ post)
-                    else:
-                        bias = encoder.b_enc[feats] - (encoder.b_dec @ post)
-                    cur = tsc_hip.project_features(acts, post.t().contiguous(), bias.contiguous(), None, relu=False)
+                    cur = post_projector(acts, relu=False)
             else:
                 cur = encoder.encode_features(acts, feats, relu=True)    # :240-241
             if ignore_endoftext:
@@ -57,6 +60,8 @@ def get_feature_scores(model, encoder, tokens_arr, feature_indices, batch_size=6
         n_pos = tokens_arr.shape[1]
         cur = cur.reshape(-1, n_pos, cur.shape[-1]).permute(0, 2, 1)  # "(b pos) n -> b n pos"
         scores.append(cur.cpu().numpy().astype(np.float16))
+    if post_projector is not None:
+        post_projector.close()
     return np.concatenate(scores, axis=0)
 
 

@@ -131,6 +131,17 @@ int tsc_encode_dense(const tsc_dict_t *d, const float *x, int64_t M, float *out,
     return run_encode(d, TSC_MODE_DENSE, a, (hipStream_t)stream);
 }
 
+int tsc_encode_dense_pre(const tsc_dict_t *d, const float *x, int64_t M, float *out, tsc_stream_t stream) {
+    int rc = check_dict_x(d, x, M);
+    if (rc) return rc;
+    if (M == 0) return TSC_OK;
+    if (!out) return tsc_fail(TSC_ERR_ARG, "null output pointer");
+    EncodeArgs a = base_args(d, x, M);
+    a.out = out;
+    a.no_relu = 1;
+    return run_encode(d, TSC_MODE_DENSE, a, (hipStream_t)stream);
+}
+
 int tsc_topk_recommended_slots(int d_sae) {
     if (d_sae <= 0) return 1;
     return tsc_encode_recommended_slots(d_sae, 0);

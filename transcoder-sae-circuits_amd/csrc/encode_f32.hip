@@ -370,7 +370,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
             float *obase = a.out + (m0 + rbase) * a.N + (n0 + cbase);
             TSC_FOR_ACC({
                 if (nok[bn] && c < lim)
-                    __builtin_nontemporal_store(v > 0.f ? v : 0.f, obase + (size_t)c * a.N + bn * 32);
+                    __builtin_nontemporal_store((v > 0.f || a.no_relu) ? v : 0.f, obase + (size_t)c * a.N + bn * 32);
             })
         } else if (MODE == TSC_MODE_SPARSE) {
             TSC_FOR_ACC({
@@ -763,6 +763,7 @@ bool pick_large(int mode, const EncodeArgs &a) {
     if (forced == 128) return false;
     if (forced == 256) return true;
     if (!a.bf16 && mode == TSC_MODE_TOPK) return false;
+    if (a.N <= CfgSmall::BN) return false;  // a skinny dictionary (tsc_hip.FeatureProjector) would waste the wide tile
     const long long tiles = (long long)((a.N + CfgLarge::BN - 1) / CfgLarge::BN) * ((a.M + CfgLarge::BM - 1) / CfgLarge::BM);
     if (mode == TSC_MODE_TOPK) return (long long)((a.N + CfgLarge::BN - 1) / CfgLarge::BN) * a.m_split >= 256;
     return tiles >= 256;
@@ -784,7 +785,7 @@ template <class C, int MODE>
 int launch(EncodeArgs a, hipStream_t stream) {
     a.n_tiles_n = (a.N + C::BN - 1) / C::BN;
     if (a.m_split <= 0)
-        a.m_split = balanced_split(a.n_tiles_n, (a.M + C::BM - 1) / C::BM, 256 * C::OCC, 64);
+        a.m_split = balanced_split(a.n_tiles_n, (a.M + C::BM - 1) / C::BM, 256 * C::OCC, 4096);
     const long long grid = (long long)a.n_tiles_n * a.m_split;
     if (grid <= 0 || grid > 0x7fffffffLL) return tsc_fail(TSC_ERR_ARG, "encode grid %lld out of range", grid);
     // the LDS-DMA kernels address the transposed operand with 32-bit lane offsets

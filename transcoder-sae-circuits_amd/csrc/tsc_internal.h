@@ -35,6 +35,7 @@ struct EncodeArgs {
     long long M;
     int K, N;
     int n_tiles_n, m_split;
+    int no_relu;         // DENSE: store the pre-activation (hook_hidden_pre) instead of relu of it
     float *out;          // DENSE
     float *tk_vals;      // TOPK: [m_split][N][topk]
     long long *tk_idx;   //

@@ -30,6 +30,7 @@ _SIGNATURES = {
     "tsc_dict_refresh": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "tsc_dict_destroy": (_c.c_int, [_c.c_void_p]),
     "tsc_encode_dense": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p]),
+    "tsc_encode_dense_pre": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p]),
     "tsc_topk_recommended_slots": (_c.c_int, [_c.c_int]),
     "tsc_set_tuning": (_c.c_int, [_c.c_char_p, _c.c_int]),
     "tsc_topk_state_reset": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
@@ -176,6 +177,14 @@ class DeviceDict:
             _check(lib().tsc_encode_topk(self._handle, x2.data_ptr(), x2.shape[0], int(token_id_base),
                                          ctypes.byref(state._struct), _stream()))
 
+    def encode_pre(self, x: torch.Tensor) -> torch.Tensor:
+        """``(x - b_dec) @ W_enc + b_enc`` (no ReLU: the reference's ``hook_hidden_pre``)."""
+        x2 = _dev(x, torch.float32, "x").reshape(-1, self.d_in)
+        out = torch.empty(x2.shape[0], self.d_sae, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _check(lib().tsc_encode_dense_pre(self._handle, x2.data_ptr(), x2.shape[0], out.data_ptr(), _stream()))
+        return out.reshape(*x.shape[:-1], self.d_sae)
+
     # ------------------------------------------------------------------ sparse
     def encode_sparse(self, x: torch.Tensor, max_active: int = 512) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """Per row the active features, value-descending: ``(feat int32 [M,cap], val [M,cap],
@@ -295,23 +304,71 @@ def topk_merge(vals: torch.Tensor, idx: torch.Tensor) -> Tuple[torch.Tensor, tor
     return ov, oi
 
 
+class FeatureProjector:
+    """``act((x - b_dec) @ Pt.T + bias)`` for a fixed handful of encoder columns ``Pt [F, d_in]``.
+
+    Six or more columns (and ``d_in % 64 == 0``) are registered as a small dictionary of their own, so
+    the projection of a long token stream runs on the MFMA encode kernel as a skinny GEMM (one 128-wide
+    column tile; 11x faster than the per-token dot products at F = 64); fewer columns, short inputs
+    and odd ``d_in`` use ``tsc_project_features``.  Make one per feature set and reuse it across batches.
+    Holds COPIES of the selected columns: rebuild it after the source dictionary changes."""
+
+    MIN_ROWS_FOR_GEMM = 1024
+    MIN_FEATURES_FOR_GEMM = 6  # measured crossover with the per-row kernel (60 + 17.5 F us vs a flat ~100 us per 65536 rows)
+
+    def __init__(self, Pt: torch.Tensor, bias: torch.Tensor, b_dec: Optional[torch.Tensor] = None):
+        self.Pt = _dev(Pt, torch.float32, "Pt").contiguous()
+        self.bias = _dev(bias, torch.float32, "bias").contiguous()
+        self.b_dec = _dev(b_dec, torch.float32, "b_dec").contiguous() if b_dec is not None else None
+        self.n_feat, self.d_in = self.Pt.shape
+        self._dict = None
+        if self.n_feat >= self.MIN_FEATURES_FOR_GEMM and self.d_in % 64 == 0:
+            pad = (-self.n_feat) % 4  # d_sae must be a multiple of 4: repeat the last column
+            pt = torch.cat([self.Pt, self.Pt[-1:].expand(pad, -1)]) if pad else self.Pt
+            bs = torch.cat([self.bias, self.bias[-1:].expand(pad)]) if pad else self.bias
+            bd = self.b_dec if self.b_dec is not None else torch.zeros(self.d_in, dtype=torch.float32, device=Pt.device)
+            self._dict = DeviceDict(pt.t().contiguous(), bs.contiguous(), bd)
+
+    def __call__(self, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+        x2 = _dev(x, torch.float32, "x").reshape(-1, x.shape[-1])
+        if self._dict is not None and x2.shape[0] >= self.MIN_ROWS_FOR_GEMM:
+            out = self._dict.encode_dense(x2) if relu else self._dict.encode_pre(x2)
+            return out[:, :self.n_feat].contiguous() if out.shape[1] != self.n_feat else out
+        return _project_rows(x2, self.Pt, self.bias, self.b_dec, relu)
+
+    def close(self) -> None:
+        if self._dict is not None:
+            self._dict.close()
+            self._dict = None
+
+
 def project_features(x: torch.Tensor, Pt: torch.Tensor, bias: torch.Tensor, b_dec: Optional[torch.Tensor] = None,
                      relu: bool = False) -> torch.Tensor:
-    """``act((x - b_dec) @ Pt.T + bias)`` for a handful of encoder columns ``Pt [F, d_in]`` ->
-    ``[M, F]``; features are processed 64 per launch."""
+    """One-shot :class:`FeatureProjector` (``[M, F]`` output)."""
     x2 = _dev(x, torch.float32, "x").reshape(-1, x.shape[-1])
-    Pt = _dev(Pt, torch.float32, "Pt")
-    bias = _dev(bias, torch.float32, "bias")
+    if (Pt.shape[0] >= FeatureProjector.MIN_FEATURES_FOR_GEMM and x2.shape[0] >= FeatureProjector.MIN_ROWS_FOR_GEMM
+            and x2.shape[1] % 64 == 0):
+        proj = FeatureProjector(Pt, bias, b_dec)
+        try:
+            return proj(x2, relu)
+        finally:
+            proj.close()
+    return _project_rows(x2, _dev(Pt, torch.float32, "Pt"), _dev(bias, torch.float32, "bias"), b_dec, relu)
+
+
+def _project_rows(x2: torch.Tensor, Pt: torch.Tensor, bias: torch.Tensor, b_dec: Optional[torch.Tensor],
+                  relu: bool) -> torch.Tensor:
+    """``tsc_project_features``: one wavefront per token row, features processed 64 per launch."""
     if b_dec is not None:
         _dev(b_dec, torch.float32, "b_dec")
     m, d_in = x2.shape
     n_feat = Pt.shape[0]
     parts = []
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x2.device):
         for s in range(0, n_feat, 64):
             pt = Pt[s:s + 64].contiguous()
             bs = bias[s:s + 64].contiguous()
-            out = torch.empty(m, pt.shape[0], dtype=torch.float32, device=x.device)
+            out = torch.empty(m, pt.shape[0], dtype=torch.float32, device=x2.device)
             _check(lib().tsc_project_features(x2.data_ptr(), m, d_in, b_dec.data_ptr() if b_dec is not None else None,
                                               pt.data_ptr(), bs.data_ptr(), pt.shape[0], int(relu), out.data_ptr(),
                                               _stream()))
