@@ -410,6 +410,16 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
             for (;;) {  // sm.pushed == sm.again == 0 and sm.f_nq[] == 0 on entry
                 if (hot) {
                     int ord = 0, blocked = 0;
+                    // This branch is cold.  Its compares are pure, so hipcc would evaluate them ahead of the
+                    // branch on every tile (and spill the resulting masks): tie their operands to the branch.
+                    float thr_c[WNB], zero = 0.f;
+                    int lim_c = lim, rbase_c = rbase, cbase_c = cbase;
+#pragma unroll
+                    for (int bn = 0; bn < WNB; ++bn) {
+                        thr_c[bn] = thr[bn];
+                        asm volatile("" : "+v"(thr_c[bn]));
+                    }
+                    asm volatile("" : "+v"(zero), "+v"(lim_c), "+v"(rbase_c), "+v"(cbase_c));
 #pragma unroll
                     for (int bm = 0; bm < WMB; ++bm)
 #pragma unroll
@@ -419,13 +429,13 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
                                 for (int r = 0; r < 16; ++r) {
                                     const int c = bm * 32 + (r & 3) + 8 * (r >> 2);
                                     const float v = acc[bm][bn][r];
-                                    if (v > 0.f && v >= thr[bn] && c < lim) {
+                                    if (v > zero && v >= thr_c[bn] && c < lim_c) {
                                         if (ord >= consumed && !blocked) {
-                                            const int col = cbase + bn * 32;
+                                            const int col = cbase_c + bn * 32;
                                             const int pos = atomicAdd(&sm.f_nq[col], 1);
                                             if (pos < QD) {
                                                 sm.q_val[col * QD + pos] = v;
-                                                sm.q_row[col * QD + pos] = (unsigned char)(rbase + c);
+                                                sm.q_row[col * QD + pos] = (unsigned char)(rbase_c + c);
                                                 sm.pushed = 1;
                                                 ++consumed;
                                             } else {
