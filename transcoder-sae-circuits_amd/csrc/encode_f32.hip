@@ -359,12 +359,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
         BODY                                                                                    \
     }
 
-#pragma unroll
-        for (int bm = 0; bm < WMB; ++bm)
-#pragma unroll
-            for (int bn = 0; bn < WNB; ++bn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[bm][bn][r] += be[bn];
+        // the bias is already in the accumulators: they start from it (see the tile loop)
 
         if (MODE == TSC_MODE_DENSE) {
             float *obase = a.out + (m0 + rbase) * a.N + (n0 + cbase);
@@ -591,7 +586,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
 #pragma unroll
             for (int bn = 0; bn < WNB; ++bn)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[bm][bn][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[bm][bn][r] = be[bn];  // start from the bias: no add in the epilogue
 
         // The order inside a k-step is pinned with sched_barrier(0): left alone, hipcc sinks every
         // fragment read to just before its first use and hoists the barrier above the MFMAs meant
