@@ -362,11 +362,26 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
         // the bias is already in the accumulators: they start from it (see the tile loop)
 
         if (MODE == TSC_MODE_DENSE) {
-            float *obase = a.out + (m0 + rbase) * a.N + (n0 + cbase);
-            TSC_FOR_ACC({
-                if (nok[bn] && c < lim)
-                    __builtin_nontemporal_store((v > 0.f || a.no_relu) ? v : 0.f, obase + (size_t)c * a.N + bn * 32);
-            })
+            if (rows_left >= BM && n0 + BN <= a.N) {
+                // Interior tile: no predicates.  The address is a scalar row base (tile origin + element row * N)
+                // plus one 32-bit lane offset per column block, so an element costs a v_max and a store.
+                const char *tile = (const char *)(a.out + m0 * a.N + n0);
+                unsigned vo[WNB];
+#pragma unroll
+                for (int bn = 0; bn < WNB; ++bn) vo[bn] = ((unsigned)rbase * (unsigned)a.N + (unsigned)(cbase + bn * 32)) * 4u;
+                const size_t row_bytes = (size_t)a.N * 4;
+                if (a.no_relu) {
+                    TSC_FOR_ACC({ __builtin_nontemporal_store(v, (float *)(tile + c * row_bytes + vo[bn])); })
+                } else {
+                    TSC_FOR_ACC({ __builtin_nontemporal_store(fmaxf(v, 0.f), (float *)(tile + c * row_bytes + vo[bn])); })
+                }
+            } else {
+                float *obase = a.out + (m0 + rbase) * a.N + (n0 + cbase);
+                TSC_FOR_ACC({
+                    if (nok[bn] && c < lim)
+                        __builtin_nontemporal_store((v > 0.f || a.no_relu) ? v : 0.f, obase + (size_t)c * a.N + bn * 32);
+                })
+            }
         } else if (MODE == TSC_MODE_SPARSE) {
             TSC_FOR_ACC({
                 if (v > 0.f && nok[bn] && c < lim) {
