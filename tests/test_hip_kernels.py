@@ -165,6 +165,25 @@ def test_every_kernel_variant_gives_the_same_results(variant):
             tsc_hip.set_tuning(key, 0)
 
 
+def test_folded_decoder_bias_under_cancellation():
+    """The LDS-DMA kernels contract the raw x and add b_enc - b_dec @ W_enc instead of subtracting b_dec
+    first.  Worst case for that: activations that sit close to a large b_dec, as in
+    a trained dictionary whose b_dec is the mean activation -- x @ W_enc and b_dec @ W_enc then cancel to
+    two digits.  The result must still meet the fp32 gate against the reference order of operations."""
+    from synthetic_dicts import make_dictionary_weights
+
+    w = make_dictionary_weights(768, 1536, seed=31, b_enc=0.0)
+    gen = torch.Generator().manual_seed(32)
+    w["b_dec"] = 3.0 * torch.randn(768, generator=gen)
+    x = w["b_dec"] + 0.05 * torch.randn(600, 768, generator=gen)
+    ref = E.encode_ref(x, w["W_enc"], w["b_enc"], w["b_dec"])
+    assert float(ref.abs().max()) < 0.1 * float((x @ w["W_enc"]).abs().max())  # the cancellation is real
+    d, _ = _dd(w)
+    out = d.encode_dense(x.to(DEV)).cpu()
+    scale = float(ref.abs().max())
+    assert float((out - ref).abs().max()) <= 1e-4 * scale, float((out - ref).abs().max()) / scale
+
+
 def test_fused_topk_matches_golden():
     import tsc_hip
 
