@@ -383,16 +383,22 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
                 })
             }
         } else if (MODE == TSC_MODE_SPARSE) {
-            TSC_FOR_ACC({
-                if (v > 0.f && nok[bn] && c < lim) {
-                    const long long row = m0 + rbase + c;
-                    const int pos = atomicAdd(a.sp_count + row, 1);
-                    if (pos < a.max_active) {
-                        a.sp_feat[row * a.max_active + pos] = n0 + cbase + bn * 32;
-                        a.sp_val[row * a.max_active + pos] = v;
-                    }
+            // append (feature, value) to the token's list; the emit is rare (a fraction of a percent of the
+            // elements), so the per-element cost is the test: interior tiles test the sign only
+            auto emit = [&](int c, int bn, float v) {
+                long long row = m0 + rbase + c;
+                asm volatile("" : "+v"(row));  // keep the address arithmetic inside the (cold) branch
+                const int pos = atomicAdd(a.sp_count + row, 1);
+                if (pos < a.max_active) {
+                    a.sp_feat[row * a.max_active + pos] = n0 + cbase + bn * 32;
+                    a.sp_val[row * a.max_active + pos] = v;
                 }
-            })
+            };
+            if (rows_left >= BM && n0 + BN <= a.N) {
+                TSC_FOR_ACC({ if (v > 0.f) emit(c, bn, v); })
+            } else {
+                TSC_FOR_ACC({ if (v > 0.f && nok[bn] && c < lim) emit(c, bn, v); })
+            }
         } else {
             // Lane-local pre-check per 32x32 block: the lane's largest value of the block against
             // its feature's k-th best (rows past M are copies of the last real row, so they cannot
