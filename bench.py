@@ -121,7 +121,11 @@ def main():
         states.append(tsc_hip.TopkState(d_sae, args.k, device))
     # inputs resident in HBM before the timed region: one distinct batch per step and dictionary
     gen = torch.Generator(device=device).manual_seed(12345 + rank)
-    n_batches = K + W
+    # one distinct batch per step while they fit in two thirds of the free HBM (196 GB = 160 steps of the default
+    # size); a longer run cycles through the pool (repeated tokens tie with their first copy, which only makes
+    # the top-k epilogue busier)
+    per_batch = len(widths) * B * D_IN * 4
+    n_batches = max(1, min(K + W, int(torch.cuda.mem_get_info(device)[0] * 0.66) // per_batch))
     xs = [torch.randn(len(widths), B, D_IN, generator=gen, device=device) for _ in range(n_batches)]
     rank_base = rank * (K + W) * B  # contiguous, disjoint token-id range per rank
 
@@ -133,7 +137,7 @@ def main():
         for i, d in enumerate(dicts):
             if timed_index is not None:
                 ev[timed_index][i][0].record()
-            d.encode_topk(xs[s][i], base, states[i])
+            d.encode_topk(xs[s % n_batches][i], base, states[i])
             if timed_index is not None:
                 ev[timed_index][i][1].record()
 
