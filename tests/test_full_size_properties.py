@@ -93,3 +93,43 @@ def test_sparse_emit_full_width_matches_dense():
     recon = d.decode_sparse(feat, val, count)
     ref = dense @ g["W_dec"] + g.get("b_dec_out", g["b_dec"])
     assert torch.allclose(recon, ref, rtol=1e-4, atol=1e-4), float((recon - ref).abs().max())
+
+
+def test_long_stream_running_topk_full_width():
+    """A longer sweep at the real width (20 calls: past the floor warm-up, so most calls reuse an older
+    cross-slot floor): the fused lists must equal an exact running top-k kept with torch on the library's
+    own dense activations, bit for bit."""
+    import tsc_hip
+
+    d_sae, k, batch, n_batches = 24576, 20, 8192, 20
+    w = make_dictionary_weights(768, d_sae, seed=41, b_enc=-0.70)
+    g = {kk: v.to(DEV) for kk, v in w.items()}
+    d = tsc_hip.DeviceDict(g["W_enc"], g["b_enc"], g["b_dec"])
+    st = tsc_hip.TopkState(d_sae, k, DEV)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    run_v = torch.zeros(k, d_sae, device=DEV)
+    run_i = torch.full((k, d_sae), -1, dtype=torch.int64, device=DEV)
+    first = None
+    for b in range(n_batches):
+        x = torch.randn(batch, 768, generator=gen, device=DEV)
+        if b == 0:
+            first = x[:512].clone()
+        elif b % 5 == 0:
+            x[100:612] = first  # the same contexts again: exact ties with older tokens
+        base = b * batch
+        d.encode_topk(x, base, st)
+        dense = d.encode_dense(x)
+        ids = torch.arange(base, base + batch, device=DEV)[:, None].expand(-1, d_sae)
+        cat_v = torch.cat([run_v, dense])          # older entries first: the stable sort keeps smaller ids ahead
+        cat_i = torch.cat([run_i, ids])
+        order = torch.sort(cat_v, dim=0, descending=True, stable=True).indices[:k]
+        run_v = torch.gather(cat_v, 0, order)
+        run_i = torch.gather(cat_i, 0, order)
+        del dense, cat_v, cat_i, ids
+    live = run_v > 0
+    exp_v = torch.where(live, run_v, torch.zeros_like(run_v)).t().contiguous()
+    exp_i = torch.where(live, run_i, torch.full_like(run_i, -1)).t().contiguous()
+    v, i = st.finalize()
+    assert st._calls == n_batches
+    assert torch.equal(v, exp_v), float((v - exp_v).abs().max())
+    assert torch.equal(i, exp_i), int((i != exp_i).sum())
