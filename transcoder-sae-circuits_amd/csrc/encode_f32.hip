@@ -643,7 +643,14 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
                     // 4 MFMAs (32 cycles each) per 16-k group: the pieces go out two per MFMA in the
                     // first group and have the other three to land
                     constexpr int PPM = (APW + BPW) / (WMB * WNB);
-                    TSC_PIN ldfrag(PAR, 1, G);
+                    // A fragment read is issued right AFTER the first MFMA of the group that runs meanwhile, not
+                    // before it: hipcc waits lgkmcnt(0) for that group's own (older) fragment, which would
+                    // otherwise also wait for the read just issued.
+#define TSC_BGROUP(FR, NEXT_READ)                                                                        \
+    _Pragma("unroll") for (int bm = 0; bm < WMB; ++bm) _Pragma("unroll") for (int bn = 0; bn < WNB; ++bn) { \
+        TSC_PIN TSC_MFMA_B(FR, bm, bn)                                                                   \
+        if (bm == 0 && bn == 0) { TSC_PIN NEXT_READ; }                                                   \
+    }
 #pragma unroll
                     for (int bm = 0; bm < WMB; ++bm)
 #pragma unroll
@@ -652,35 +659,42 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
 #pragma unroll
                             for (int jj = 0; jj < PPM; ++jj) dma_piece((bm * WNB + bn) * PPM + jj, xp, wp, PAR ^ 1, la, lb);
                             TSC_PIN TSC_MFMA_B(F, bm, bn)
+                            if (bm == 0 && bn == 0) { TSC_PIN ldfrag(PAR, 1, G); }
                         }
-                    TSC_PIN ldfrag(PAR, 2, F);
-                    TSC_PIN TSC_MFMA_BALL(G)
-                    TSC_PIN ldfrag(PAR, 3, G);
-                    TSC_PIN TSC_MFMA_BALL(F)
+                    TSC_BGROUP(G, ldfrag(PAR, 2, F))
+                    TSC_BGROUP(F, ldfrag(PAR, 3, G))
+#pragma unroll
+                    for (int bn = 0; bn < WNB; ++bn) { TSC_PIN TSC_MFMA_B(G, 0, bn) }
                     TSC_PIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     TSC_PIN ldfrag(PAR ^ 1, 0, F);
-                    TSC_PIN TSC_MFMA_BALL(G)
+#pragma unroll
+                    for (int bm = 1; bm < WMB; ++bm)
+#pragma unroll
+                        for (int bn = 0; bn < WNB; ++bn) { TSC_PIN TSC_MFMA_B(G, bm, bn) }
                     TSC_PIN
+#undef TSC_BGROUP
                 } else {
-                    TSC_PIN ldfrag(PAR, 1, G);
-    #pragma unroll
+                    // (fragment reads one MFMA step late: see the bf16 branch)
+#pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         TSC_PIN
-    #pragma unroll
+#pragma unroll
                         for (int jj = 0; jj < PPS; ++jj) dma_piece(s * PPS + jj, xp, wp, PAR ^ 1, la, lb);
                         TSC_PIN TSC_MFMA_S(F, s)
+                        if (s == 0) { TSC_PIN ldfrag(PAR, 1, G); }
                     }
-                    TSC_PIN ldfrag(PAR, 2, F);
-    #pragma unroll
+#pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         TSC_PIN
-    #pragma unroll
+#pragma unroll
                         for (int jj = 0; jj < PPS; ++jj) dma_piece((4 + s) * PPS + jj, xp, wp, PAR ^ 1, la, lb);
                         TSC_PIN TSC_MFMA_S(G, s)
+                        if (s == 0) { TSC_PIN ldfrag(PAR, 2, F); }
                     }
+                    TSC_PIN TSC_MFMA_S(F, 0)
                     TSC_PIN ldfrag(PAR, 3, G);
-                    TSC_PIN TSC_MFMA(F, 0, 4)
+                    TSC_PIN TSC_MFMA(F, 1, 4)
                     TSC_PIN TSC_MFMA(G, 0, 2)
                     TSC_PIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed
                     __syncthreads();
