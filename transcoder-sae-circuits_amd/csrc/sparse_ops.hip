@@ -66,12 +66,15 @@ __global__ __launch_bounds__(256) void decode_rows_kernel(const float *W_dec, in
     }
 }
 
-// grid = M; each thread owns float4 column chunks and walks the token's active list
+// grid = M; each thread owns float4 column chunks and walks the token's active list, U rows in flight
+// (U = 8 for short inputs, where one workgroup per token leaves the pass latency-bound; U = 1 for long ones,
+// where occupancy hides the latency and the registers are better spent on more resident workgroups)
+template <int U>
 __global__ __launch_bounds__(256) void decode_sparse_kernel(const float *W_dec, const float *bias, int d_out,
                                                            const int *feat, const float *val,
                                                            const int *count, int max_active, float *recon) {
-    __shared__ int sf[256];
-    __shared__ float sv[256];
+    __shared__ int sf[256 + 8];
+    __shared__ float sv[256 + 8];
     const long long m = blockIdx.x;
     int c = count[m];
     if (c > max_active) c = max_active;
@@ -87,14 +90,31 @@ __global__ __launch_bounds__(256) void decode_sparse_kernel(const float *W_dec, 
             sf[threadIdx.x] = feat[m * max_active + base + threadIdx.x];
             sv[threadIdx.x] = val[m * max_active + base + threadIdx.x];
         }
+        if (threadIdx.x < 8) {  // padding of the last group of eight
+            sf[nb + threadIdx.x] = 0;
+            sv[nb + threadIdx.x] = 0.f;
+        }
         __syncthreads();
-        for (int e = 0; e < nb; ++e) {
-            const f32x4 *src = (const f32x4 *)(W_dec + (long long)sf[e] * d_out);
-            const float v = sv[e];
+        // (entries past nb are staged as feature 0 with value 0)
+        for (int e0 = 0; e0 < nb; e0 += U) {
+            f32x4 w[U][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ch = threadIdx.x + 256 * j;
-                if (ch < chunks) acc[j] += src[ch] * v;
+            for (int u = 0; u < U; ++u) {
+                const f32x4 *src = (const f32x4 *)(W_dec + (long long)sf[e0 + u] * d_out);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ch = threadIdx.x + 256 * j;
+                    if (ch < chunks) w[u][j] = src[ch];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float v = sv[e0 + u];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ch = threadIdx.x + 256 * j;
+                    if (ch < chunks) acc[j] += w[u][j] * v;
+                }
             }
         }
     }
@@ -250,8 +270,12 @@ int tsc_launch_decode_sparse(const float *W_dec, const float *bias, int d_out, c
                              hipStream_t stream) {
     if (M <= 0) return TSC_OK;
     if (d_out > 4096) return tsc_fail(TSC_ERR_UNSUPPORTED, "d_out %d exceeds 4096", d_out);
-    hipLaunchKernelGGL(decode_sparse_kernel, dim3((unsigned)M), dim3(256), 0, stream, W_dec, bias, d_out,
-                       feat, val, count, max_active, recon);
+    if (M <= 2048)
+        hipLaunchKernelGGL(decode_sparse_kernel<8>, dim3((unsigned)M), dim3(256), 0, stream, W_dec, bias, d_out,
+                           feat, val, count, max_active, recon);
+    else
+        hipLaunchKernelGGL(decode_sparse_kernel<1>, dim3((unsigned)M), dim3(256), 0, stream, W_dec, bias, d_out,
+                           feat, val, count, max_active, recon);
     TSC_HIP_CHECK(hipGetLastError());
     return TSC_OK;
 }
