@@ -39,6 +39,7 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDA = BK + 4;  // 144-byte rows: ds_read_b128 of 16 consecutive rows hits 16 distinct slots
 constexpr int QD = 4;   // candidate slots per feature and round
+constexpr int SPQ = 512;  // staged sparse entries per tile (more go straight to HBM)
 constexpr int KL = 20;  // list length up to which the lists' values are mirrored in LDS
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -76,7 +77,10 @@ struct __attribute__((aligned(16))) Smem {
     unsigned char f_cnt[C::BN];
     float f_floor[C::BN];  // k-th best of the feature over all slots when the launch started (0: unknown)
     int pushed, again;  // round flags: somebody pushed / somebody found its feature's slots full
-    int pad[2];
+    int sp_n[2];        // SPARSE: entries staged in sp_val/sp_loc by the tile of this parity
+    // SPARSE: the tile's positive activations, staged so that their global appends go out together
+    float sp_val[LLDS ? 1 : SPQ];
+    int sp_loc[LLDS ? 1 : SPQ];  // (row in tile << 8) | column in tile
 };
 
 __device__ __forceinline__ bool ranks_below(float v, long long id, float w, long long wid) {
@@ -342,6 +346,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
         }
     };
 
+    int ep_tiles = 0;
     auto epilogue = [&](f32x16 (&acc)[WMB][WNB], const long long m0) {
         // ---------------------------------------------------------------- epilogues
         // C layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -385,19 +390,41 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
         } else if (MODE == TSC_MODE_SPARSE) {
             // append (feature, value) to the token's list; the emit is rare (a fraction of a percent of the
             // elements), so the per-element cost is the test: interior tiles test the sign only
-            auto emit = [&](int c, int bn, float v) {
-                long long row = m0 + rbase + c;
-                asm volatile("" : "+v"(row));  // keep the address arithmetic inside the (cold) branch
+            // Appending straight from the accumulator scan would serialise one global atomic round trip per
+            // element and lane.  Instead the tile's positives are staged in LDS (an LDS atomic each), and after
+            // one barrier every thread takes staged entries and issues their appends together: one round trip
+            // per tile.  The counter alternates with the tile parity, so its reset needs no second barrier.
+            const int par = ep_tiles & 1;
+            ++ep_tiles;
+            auto direct = [&](long long row, int col, float v) {
                 const int pos = atomicAdd(a.sp_count + row, 1);
                 if (pos < a.max_active) {
-                    a.sp_feat[row * a.max_active + pos] = n0 + cbase + bn * 32;
+                    a.sp_feat[row * a.max_active + pos] = n0 + col;
                     a.sp_val[row * a.max_active + pos] = v;
+                }
+            };
+            auto emit = [&](int c, int bn, float v) {
+                int loc = ((rbase + c) << 8) | (cbase + bn * 32);
+                asm volatile("" : "+v"(loc));  // keep the arithmetic inside the (cold) branch
+                const int q = atomicAdd(&sm.sp_n[par], 1);
+                if (q < SPQ) {
+                    sm.sp_val[q] = v;
+                    sm.sp_loc[q] = loc;
+                } else {
+                    direct(m0 + (loc >> 8), loc & 255, v);
                 }
             };
             if (rows_left >= BM && n0 + BN <= a.N) {
                 TSC_FOR_ACC({ if (v > 0.f) emit(c, bn, v); })
             } else {
                 TSC_FOR_ACC({ if (v > 0.f && nok[bn] && c < lim) emit(c, bn, v); })
+            }
+            __syncthreads();
+            const int staged = sm.sp_n[par] < SPQ ? sm.sp_n[par] : SPQ;
+            if (tid == 0) sm.sp_n[par ^ 1] = 0;  // last read before this tile's barrier
+            for (int e = tid; e < staged; e += NT) {
+                const int loc = sm.sp_loc[e];
+                direct(m0 + (loc >> 8), loc & 255, sm.sp_val[e]);
             }
         } else {
             // Lane-local pre-check per 32x32 block: the lane's largest value of the block against
@@ -595,6 +622,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
             sstore(0, 0);
         }
     }
+    if (MODE == TSC_MODE_SPARSE && tid == 0) sm.sp_n[0] = sm.sp_n[1] = 0;
     __syncthreads();
     Frag F, G;
     if (mt < n_mtiles) ldfrag(0, 0, F);
