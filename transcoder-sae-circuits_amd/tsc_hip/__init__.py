@@ -186,9 +186,11 @@ class DeviceDict:
         return out.reshape(*x.shape[:-1], self.d_sae)
 
     # ------------------------------------------------------------------ sparse
-    def encode_sparse(self, x: torch.Tensor, max_active: int = 512) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def encode_sparse(self, x: torch.Tensor, max_active: int = 512, check_capacity: bool = True) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """Per row the active features, value-descending: ``(feat int32 [M,cap], val [M,cap],
-        count int32 [M])``.  Grows the capacity and retries if a row overflows it."""
+        count int32 [M])``.  Grows the capacity and retries if a row overflows it -- which costs one
+        host sync per call; ``check_capacity=False`` skips that (the caller then checks
+        ``count.max() <= feat.shape[1]`` itself, e.g. once for a whole pass over many dictionaries)."""
         x2 = _dev(x, torch.float32, "x").reshape(-1, self.d_in)
         m = x2.shape[0]
         cap = max(1, min(int(max_active), MAX_ACTIVE_LIMIT, self.d_sae))
@@ -199,6 +201,8 @@ class DeviceDict:
             with torch.cuda.device(x.device):
                 _check(lib().tsc_encode_sparse(self._handle, x2.data_ptr(), m, cap, feat.data_ptr(), val.data_ptr(),
                                                count.data_ptr(), _stream()))
+            if not check_capacity:
+                return feat, val, count
             worst = int(count.max()) if m else 0
             if worst <= cap:
                 return feat, val, count
