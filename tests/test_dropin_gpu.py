@@ -279,3 +279,24 @@ def test_activation_dictionary_and_sweep():
         xf = x.reshape(24 * 16, -1).cpu()
         rv, ri = topk_stream_ref(xf, w, k=5)
         _assert_topk_equal(res[name][0], res[name][1], rv, ri, E.encode_ref(xf, w["W_enc"], w["b_enc"], w["b_dec"]))
+
+
+def test_sweep_checkpoint_and_resume_on_gpu(tmp_path):
+    """MaxActSweep.save / load through the HIP engine: interrupted + resumed == uninterrupted."""
+    import topk_scan
+    from load_model_and_encoders import build_transcoder
+
+    g, w, xs, n_seq, n_pos = gi.g2_inputs()
+    tc = build_transcoder(w, 8, DEV)
+    x = xs.to(DEV)
+    whole = topk_scan.MaxActSweep({"mlp_8": tc}, k=20, distributed=False)
+    whole.feed({"mlp_8": x}, 0)
+    ev, ei = whole.result()["mlp_8"]
+    a = topk_scan.MaxActSweep({"mlp_8": tc}, k=20, distributed=False)
+    a.feed({"mlp_8": x[:1500]}, 0)
+    a.save(str(tmp_path / "s.pt"))
+    b = topk_scan.MaxActSweep({"mlp_8": tc}, k=20, distributed=False)
+    b.load(str(tmp_path / "s.pt"))
+    b.feed({"mlp_8": x[1500:]}, b.tokens_seen)
+    v, i = b.result()["mlp_8"]
+    assert torch.equal(v, ev) and torch.equal(i, ei)

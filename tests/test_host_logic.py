@@ -99,11 +99,41 @@ class _OracleEngine:
     def finalize(self):
         return self.state
 
+    def load(self, vals, idx):
+        self.state = (vals.clone(), idx.clone())
+
     @staticmethod
     def merge(vals, idx):
         from oracle.topk_ref import topk_merge_ref
 
         return topk_merge_ref([(vals[i], idx[i]) for i in range(vals.shape[0])], k=vals.shape[-1])
+
+
+def test_sweep_checkpoint_and_resume(tmp_path):
+    """A sweep saved half way and resumed in a new object ends with the lists of an uninterrupted one;
+    the file holds plain tensors only (loadable with weights_only=True)."""
+    import topk_scan
+    from oracle.topk_ref import topk_stream_ref
+    from synthetic_dicts import make_dictionary_weights
+
+    ws = {n: make_dictionary_weights(64, 96, seed=i, b_enc=-0.3) for i, n in enumerate(("z_0", "mlp_0"))}
+    x = torch.randn(600, 64, generator=torch.Generator().manual_seed(0))
+    mk = lambda: topk_scan.MaxActSweep(ws, k=5, engine_factory=lambda w: _OracleEngine(w, 5), distributed=False)
+    a = mk()
+    a.feed({n: x[:250] for n in ws}, 0)
+    a.save(str(tmp_path / "sweep.pt"))
+    sd = torch.load(str(tmp_path / "sweep.pt"), weights_only=True)
+    assert int(sd["tokens_seen"]) == 250 and set(sd) == {"tokens_seen", "k", "z_0.vals", "z_0.idx", "mlp_0.vals", "mlp_0.idx"}
+    b = mk()
+    b.load(str(tmp_path / "sweep.pt"))
+    b.feed({n: x[250:] for n in ws}, b.tokens_seen)
+    res = b.result()
+    for n, w in ws.items():
+        ev, ei = topk_stream_ref(x, w, k=5)
+        assert torch.equal(res[n][0], ev) and torch.equal(res[n][1], ei)
+    with pytest.raises(ValueError):
+        topk_scan.MaxActSweep(ws, k=6, engine_factory=lambda w: _OracleEngine(w, 6), distributed=False).load(
+            str(tmp_path / "sweep.pt"))
 
 
 def _worker(rank, world, port, out_dir):

@@ -35,6 +35,11 @@ class HipTopkEngine:
     def finalize(self) -> Tuple[torch.Tensor, torch.Tensor]:
         return self.state.finalize()
 
+    def load(self, vals: torch.Tensor, idx: torch.Tensor) -> None:
+        """Resume from finalized lists (they become the running state)."""
+        dev = self.state.device
+        self.state.load(vals.to(dev, torch.float32), idx.to(dev, torch.int64))
+
     @staticmethod
     def merge(vals: torch.Tensor, idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         return tsc_hip.topk_merge(vals.contiguous(), idx.contiguous())
@@ -104,6 +109,32 @@ class MaxActSweep:
                 raise ValueError("all dictionaries must be fed the same number of token rows per call")
             self.engines[name].update(x2, token_id_base)
         self.tokens_seen += n or 0
+
+    # ---- resume point (a compact top-k file instead of the reference's dump of
+    # dense activations, src/max_activating.py:117-120).  Plain tensors only: torch.load(weights_only=True).
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """This rank's finalized lists (NOT merged across ranks) and how many token rows went in."""
+        out = {"tokens_seen": torch.tensor(self.tokens_seen, dtype=torch.int64), "k": torch.tensor(self.k)}
+        for name, eng in self.engines.items():
+            vals, idx = eng.finalize()
+            out[f"{name}.vals"], out[f"{name}.idx"] = vals.cpu(), idx.cpu()
+        return out
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        if int(sd["k"]) != self.k:
+            raise ValueError(f"checkpoint holds top-{int(sd['k'])} lists, this sweep keeps top-{self.k}")
+        missing = [n for n in self.engines if f"{n}.vals" not in sd]
+        if missing:
+            raise KeyError(f"checkpoint has no lists for {missing}")
+        for name, eng in self.engines.items():
+            eng.load(sd[f"{name}.vals"], sd[f"{name}.idx"])
+        self.tokens_seen = int(sd["tokens_seen"])
+
+    def save(self, path: str) -> None:
+        torch.save(self.state_dict(), path)
+
+    def load(self, path: str) -> None:
+        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
 
     def result(self) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
         names = list(self.engines)
