@@ -822,18 +822,19 @@ bool use_dma() { return tuning().staging == 0; }
 bool use_lds_lists() { return tuning().lists == 0; }
 
 // Auto geometry.  256x256 (8 waves, one workgroup per CU) reads each operand byte from L2 half as often and
-// issues fewer non-MFMA instructions per MFMA: it is the faster one for the dense and sparse epilogues and for
-// bf16 (fp32 dense 146 vs 143 TFLOP/s; bf16 top-k 965 vs 915, 1000 vs 760 at d_sae = 131072) as long as its
-// grid still covers the chip.  The fp32 fused top-k keeps 128x128, where the lists' values fit in LDS next
-// to two workgroups per CU (equal speed, no register spills).
+// issues fewer non-MFMA instructions per MFMA: fp32 dense 148 vs 146 TFLOP/s, bf16 top-k 965 vs 915 (1000 vs
+// 760 at d_sae = 131072); for the fp32 fused top-k the two are equally fast, and the wide tile cuts the L2 miss
+// traffic from 9.7 to 1.9 GB per launch.  It is used whenever its grid still covers the chip; short inputs
+// and skinny dictionaries take 128x128.
 bool pick_large(int mode, const EncodeArgs &a) {
     const int forced = a.bf16 ? tuning().bf16_tile : tuning().f32_tile;
     if (forced == 128) return false;
     if (forced == 256) return true;
-    if (!a.bf16 && mode == TSC_MODE_TOPK) return false;
     if (a.N <= CfgSmall::BN) return false;  // a skinny dictionary (tsc_hip.FeatureProjector) would waste the wide tile
     const long long tiles = (long long)((a.N + CfgLarge::BN - 1) / CfgLarge::BN) * ((a.M + CfgLarge::BM - 1) / CfgLarge::BM);
-    if (mode == TSC_MODE_TOPK) return (long long)((a.N + CfgLarge::BN - 1) / CfgLarge::BN) * a.m_split >= 256;
+    if (mode == TSC_MODE_TOPK)  // the slots are fixed by the state: every one of them must get a wide tile
+        return (long long)((a.N + CfgLarge::BN - 1) / CfgLarge::BN) * a.m_split >= 256 &&
+               (a.M + CfgLarge::BM - 1) / CfgLarge::BM >= a.m_split;
     return tiles >= 256;
 }
 
@@ -921,7 +922,7 @@ int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream) {
 // slot count that makes the fused top-k grid a whole number of waves of resident workgroups
 int tsc_encode_recommended_slots(int d_sae, int bf16) {
     const int forced = bf16 ? tuning().bf16_tile : tuning().f32_tile;
-    const bool large = forced == 256 || (forced != 128 && bf16);
+    const bool large = forced != 128;
     if (large) return balanced_split((d_sae + CfgLarge::BN - 1) / CfgLarge::BN, 1 << 30, 256 * CfgLarge::OCC, 16);
     return balanced_split((d_sae + CfgSmall::BN - 1) / CfgSmall::BN, 1 << 30, 256 * CfgSmall::OCC, 16);
 }
