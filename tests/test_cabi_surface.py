@@ -62,3 +62,29 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/tsc_hip.h is the contract a non-Python caller compiles against: it must be valid C99 on its own
+    and the state struct must have the layout the ctypes binding assumes."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "tsc_hip.h"\n'
+        "int main(void){ printf(\"%zu %zu %zu %zu\\n\", sizeof(tsc_topk_state_t), offsetof(tsc_topk_state_t, d_sae),"
+        " offsetof(tsc_topk_state_t, flags), offsetof(tsc_topk_state_t, floor)); return 0; }\n")
+    exe = tmp_path / "t"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", f"-I{inc}", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    import ctypes
+
+    import tsc_hip
+
+    st = tsc_hip._TopkStateStruct
+    assert [int(v) for v in out] == [ctypes.sizeof(st), st.d_sae.offset, st.flags.offset, st.floor.offset]
