@@ -12,12 +12,18 @@ Weights are seeded random-init with the reference's init statistics, activations
 N(0,1) (no checkpoints or datasets offline): ``"data": "synthetic"``.
 
 Contract: ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.
-N > 1 is launched by torch.distributed.run; ranks own disjoint token-id ranges (weak scaling), the
-only collective is the final all-gather of the finished lists followed by a local merge.
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment starts N fresh rank processes
+(``python -m torch.distributed.run``) BEFORE this process makes any GPU call, and exits with their
+status; under ``torch.distributed.run`` (WORLD_SIZE set) the process is one rank.  Ranks own disjoint
+token-id ranges (weak scaling); the only collective is the final all-gather of the finished lists
+followed by a local merge.  After the timed region the lists are verified against the library's own
+dense activations of the last batch (``"verified"``), outside the timing.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,8 +36,9 @@ import torch  # noqa: E402
 
 D_IN = 768
 PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
-PMC_FABRIC_BYTES_PER_LAUNCH = 1.870e9 + 3.9e6  # FETCH_SIZE x2 + WRITE_SIZE, see roofline.traffic below
+PEAK_HBM_TBS = 8.0
 ZSAE_WIDE_LAYERS = (5, 7)
+TRAFFIC_PROFILES = ("profiles/r02_encode_topk_pmc.json", "profiles/r01_encode_topk_pmc_v9.json")
 
 
 def dictionary_widths():
@@ -55,31 +62,214 @@ def make_device_dictionary(d_sae, seed, device):
     return W_enc, b_enc, b_dec
 
 
-def cpu_baseline(tokens, threads):
-    """The oracle (CPU port of the reference path: torch sgemm encode + torch.topk running top-k)
-    on ONE 24576-wide dictionary, converted to positions/s of the 24-dictionary workload."""
-    from oracle.topk_ref import topk_stream_ref
+# ----------------------------------------------------------------------------- engine
+class HipEngine:
+    """The product path: libtsc_hip.so through the ctypes binding.  (``--engine-module`` lets the CPU
+    tests of the N > 1 launcher substitute a stand-in with the same five methods; nothing else does.)"""
+
+    name = "hip"
+
+    def __init__(self, local_rank, one_gpu):
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        self.device = torch.device("cuda", 0 if one_gpu else local_rank)
+        torch.cuda.set_device(self.device)
+        import tsc_hip
+
+        self.tsc = tsc_hip
+
+    def make_dict(self, W_enc, b_enc, b_dec):
+        return self.tsc.DeviceDict(W_enc, b_enc, b_dec)
+
+    def make_state(self, d_sae, k):
+        return self.tsc.TopkState(d_sae, k, self.device)
+
+    def encode_topk(self, d, x, base, st):
+        d.encode_topk(x, base, st)
+
+    def encode_dense(self, d, x):
+        return d.encode_dense(x)
+
+    def finalize(self, st):
+        return st.finalize()
+
+    def merge(self, v, i):
+        return self.tsc.topk_merge(v.to(self.device), i.to(self.device))
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def timer(self):
+        return _EventTimer()
+
+    def free_bytes(self):
+        return torch.cuda.mem_get_info(self.device)[0]
+
+
+class _EventTimer:
+    """HIP events recorded on the stream the kernels are launched on (torch's current stream, which is the
+    stream ``tsc_hip`` passes to every entry point)."""
+
+    def __init__(self):
+        self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def start(self):
+        self.a.record()
+
+    def stop(self):
+        self.b.record()
+
+    def ms(self):
+        return self.a.elapsed_time(self.b)
+
+
+# ----------------------------------------------------------------------------- verification
+def verify_slice(engine, d, x, base, vals, idx, chunk=16384):
+    """Exact check of finished lists ``(vals, idx) [d_sae, k]`` against the library's own dense activations of
+    one batch ``x`` (token ids base ..): every token of the batch that outranks a feature's k-th entry must be
+    in that feature's list, and every list entry that names a token of the batch must carry exactly that
+    token's activation.  Ranking rule: value descending, token id ascending, positives only."""
+    k = vals.shape[1]
+    kth_v, kth_i = vals[:, k - 1], idx[:, k - 1]
+    full = kth_i >= 0
+    big = torch.iinfo(torch.int64).max
+    kth_i = torch.where(full, kth_i, torch.full_like(kth_i, big))  # a short list admits every positive value
+    ok = True
+    sorted_ok = bool((vals[:, :-1] >= vals[:, 1:]).all())
+    tie = (vals[:, :-1] == vals[:, 1:]) & (idx[:, 1:] >= 0)
+    sorted_ok = sorted_ok and bool((idx[:, :-1][tie] < idx[:, 1:][tie]).all())
+    for s in range(0, x.shape[0], chunk):
+        dense = engine.encode_dense(d, x[s:s + chunk])                       # [c, d_sae]
+        c = dense.shape[0]
+        ids = torch.arange(base + s, base + s + c, device=dense.device)[:, None]
+        should = (dense > 0) & ((dense > kth_v) | ((dense == kth_v) & (ids <= kth_i)))
+        n_should = should.sum(dim=0)
+        inside = (idx >= base + s) & (idx < base + s + c)                     # [d_sae, k]
+        rows = torch.where(inside, idx - (base + s), torch.zeros_like(idx))
+        got = torch.gather(dense.t(), 1, rows)                                # dense[row, feature]
+        ok = ok and bool((got[inside] == vals[inside]).all()) and bool((inside.sum(dim=1) == n_should).all())
+        del dense, should, got
+    return ok and sorted_ok
+
+
+# ----------------------------------------------------------------------------- CPU baseline
+def _cpu_info():
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+                cores.add((phys, core))
+    except OSError:
+        pass
+    return model, len(cores) or None
+
+
+def cpu_baseline(tokens_all, tokens_one):
+    """the oracle (CPU port of the reference path, torch fp32) on config-1-shaped input
+    (one 24576-wide dictionary, x ~ N(0,1)), two legs -- (i) the reference-shaped single-feature scan
+    (max_act_analysis.py:215-251: full encode per batch, keep one column, argsort at the end) and (ii) the
+    all-feature running top-20 (torch.topk over cat([state, batch])) -- each with all the cores this job may
+    use and with one core; one warm-up batch, median of three runs.  ``value`` is leg (ii) on all cores
+    converted to positions/s of the 24-dictionary workload."""
+    import statistics
+
+    from oracle.encode_ref import encode_ref
+    from oracle.topk_ref import active_examples_ref, topk_stream_ref
     from synthetic_dicts import make_dictionary_weights
 
-    torch.set_num_threads(threads)
+    model, phys = _cpu_info()
+    share = min(16, os.cpu_count() or 1)  # the GPU box grants 16 CPUs per GPU whatever os.cpu_count() says
     w = make_dictionary_weights(D_IN, 24576, seed=8, b_enc=-0.70)
-    x = torch.randn(tokens + 4096, D_IN, generator=torch.Generator().manual_seed(0))
-    topk_stream_ref(x[:4096], w, k=20, batch_tokens=4096, exact_ties=False)  # warm-up
-    t0 = time.perf_counter()
-    topk_stream_ref(x[4096:], w, k=20, batch_tokens=16384, exact_ties=False)
-    dt = time.perf_counter() - t0
+    x = torch.randn(max(tokens_all, tokens_one) + 2048, D_IN, generator=torch.Generator().manual_seed(0))
+    batch = 16384  # 128 sequences x 128 positions, max_act_analysis.py:25
+
+    def leg_single(xs):
+        cols = [encode_ref(xs[s:s + batch], w["W_enc"], w["b_enc"], w["b_dec"])[:, 4242] for s in range(0, xs.shape[0], batch)]
+        return active_examples_ref(torch.cat(cols).reshape(-1, 128))
+
+    def leg_all(xs):
+        return topk_stream_ref(xs, w, k=20, batch_tokens=batch, exact_ties=False)
+
+    legs = {}
+    for threads, n in ((share, tokens_all), (1, tokens_one)):
+        torch.set_num_threads(threads)
+        for name, fn in (("single_feature_scan", leg_single), ("all_feature_running_topk", leg_all)):
+            fn(x[:2048])  # warm-up
+            times = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                fn(x[2048:2048 + n])
+                times.append(time.perf_counter() - t0)
+            legs[f"{name}@{threads}"] = {"tokens": n, "threads": threads, "median_s": statistics.median(times),
+                                         "dictionary_tokens_per_s": n / statistics.median(times)}
+    torch.set_num_threads(share)
     units = sum(wd for _, _, wd in dictionary_widths()) / 24576.0
+    main = legs[f"all_feature_running_topk@{share}"]
     return {
-        "value": tokens / dt / units,
+        "value": main["dictionary_tokens_per_s"] / units,
         "unit": "positions/s",
-        "cores": threads,
+        "cores": share,
         "kind": "port",
-        "sample": f"{tokens} tokens x one 24576-wide fp32 dictionary, batch 16384, k=20 in {dt:.1f} s "
-                  f"({tokens / dt:.0f} dictionary-tokens/s), divided by the {units:.0f} such units per position",
+        "cpu_model": model,
+        "physical_cores_on_host": phys,
+        "sample": f"{tokens_all} tokens ({tokens_one} for the 1-thread legs) x one 24576-wide fp32 dictionary, batch 16384, "
+                  f"k=20, 1 warm-up, median of 3; value = leg all_feature_running_topk@{share} "
+                  f"({main['dictionary_tokens_per_s']:.0f} dictionary-tokens/s) / the {units:.0f} such units per position",
+        "legs": legs,
     }
 
 
-def main():
+# ----------------------------------------------------------------------------- traffic
+def measured_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the tracked rocprofv3 PMC summary (collected in
+    separate --pmc passes, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes)."""
+    for rel in TRAFFIC_PROFILES:
+        path = os.path.join(REPO, rel)
+        if not os.path.exists(path):
+            continue
+        try:
+            prof = json.load(open(path))
+        except ValueError:
+            continue
+        if "bench_shape" in prof:  # round-2 format: one entry per launch shape of the bench
+            return prof["bench_shape"], rel
+        der = prof.get("derived", {})
+        fetch = next((v for k, v in der.items() if k.startswith("fetch_bytes_per_launch")), None)
+        write = next((v for k, v in der.items() if k.startswith("write_bytes_per_launch")), None)
+        if fetch is not None:
+            return {"d_sae": 24576, "tokens_per_launch": 16384, "bytes_per_launch": fetch + (write or 0.0),
+                    "algorithmic_bytes_per_launch": der.get("algorithmic_bytes_per_launch"),
+                    "note": "L2 fabric side incl. Infinity Cache hits; measured at 16384 tokens per launch"}, rel
+    return None, None
+
+
+# ----------------------------------------------------------------------------- launcher
+def launch_ranks(args, argv):
+    """Parent of an N > 1 run: starts N rank processes and relays their exit status.  Makes no GPU call
+    (``torch.cuda.device_count()`` does not initialise the runtime on this image)."""
+    n = args.gpus
+    if args.engine_module is None and not args.rehearse_on_one_gpu:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible; refusing to report a "
+                  f"{have}-GPU number as a {n}-GPU one (use --rehearse-on-one-gpu to rehearse the N-rank path on one GPU)",
+                  file=sys.stderr)
+            return 2
+    port = os.environ.get("MASTER_PORT") or str(29400 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
@@ -89,109 +279,159 @@ def main():
     # a larger one amortises the per-launch head and tail (16384: 146.3, 32768: 147.4, 65536: 148.4 TFLOP/s).
     ap.add_argument("--tokens-per-step", type=int, default=65536)
     ap.add_argument("--k", type=int, default=20)
-    ap.add_argument("--cpu-tokens", type=int, default=65536)
+    ap.add_argument("--cpu-tokens", type=int, default=32768)
+    ap.add_argument("--cpu-tokens-one-thread", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-config4", action="store_true")
     # rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0, collectives over gloo
     ap.add_argument("--rehearse-on-one-gpu", action="store_true")
-    args = ap.parse_args()
+    # tests only: comma-separated dictionary widths instead of the config's 24, and a stand-in engine module
+    ap.add_argument("--dict-widths", default=None)
+    ap.add_argument("--engine-module", default=None)
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    device = torch.device("cuda", 0 if args.rehearse_on_one_gpu else local_rank)
-    torch.cuda.set_device(device)
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            raise SystemExit(launch_ranks(args, argv))
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                             f"--nproc-per-node {args.gpus}")
+
+    if args.engine_module:
+        import importlib
+
+        engine = importlib.import_module(args.engine_module).Engine(local_rank)
+    else:
+        engine = HipEngine(local_rank, args.rehearse_on_one_gpu)
+    device = engine.device
+    host_collectives = args.rehearse_on_one_gpu or device.type != "cuda"
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_on_one_gpu:
+        if host_collectives:
             import datetime
 
-            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
         else:
             dist.init_process_group("nccl", device_id=device)
 
-    import tsc_hip
-
     B, K, W = args.tokens_per_step, args.steps, args.warmup
-    widths = dictionary_widths()
+    if args.dict_widths:
+        widths = [("test", i, int(w)) for i, w in enumerate(args.dict_widths.split(","))]
+    else:
+        widths = dictionary_widths()
     dicts, states = [], []
     for i, (_, _, d_sae) in enumerate(widths):
         W_enc, b_enc, b_dec = make_device_dictionary(d_sae, 1000 + i, device)
-        dicts.append(tsc_hip.DeviceDict(W_enc, b_enc, b_dec))
-        states.append(tsc_hip.TopkState(d_sae, args.k, device))
+        dicts.append(engine.make_dict(W_enc, b_enc, b_dec))
+        states.append(engine.make_state(d_sae, args.k))
     # inputs resident in HBM before the timed region: one distinct batch per step and dictionary
     gen = torch.Generator(device=device).manual_seed(12345 + rank)
     # one distinct batch per step while they fit in two thirds of the free HBM (196 GB = 160 steps of the default
     # size); a longer run cycles through the pool (repeated tokens tie with their first copy, which only makes
     # the top-k epilogue busier)
     per_batch = len(widths) * B * D_IN * 4
-    n_batches = max(1, min(K + W, int(torch.cuda.mem_get_info(device)[0] * 0.66) // per_batch))
+    n_batches = max(1, min(K + W, int(engine.free_bytes() * 0.66) // per_batch))
     xs = [torch.randn(len(widths), B, D_IN, generator=gen, device=device) for _ in range(n_batches)]
     rank_base = rank * (K + W) * B  # contiguous, disjoint token-id range per rank
 
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in widths]
-          for _ in range(K)]
+    ev = [[engine.timer() for _ in widths] for _ in range(K)]
 
     def step(s, timed_index=None):
         base = rank_base + s * B
         for i, d in enumerate(dicts):
             if timed_index is not None:
-                ev[timed_index][i][0].record()
-            d.encode_topk(xs[s % n_batches][i], base, states[i])
+                ev[timed_index][i].start()
+            engine.encode_topk(d, xs[s % n_batches][i], base, states[i])
             if timed_index is not None:
-                ev[timed_index][i][1].record()
+                ev[timed_index][i].stop()
 
     def finish():
-        outs = [st.finalize() for st in states]
+        outs = [engine.finalize(st) for st in states]
         if world > 1:
             from topk_scan import allgather_merge_many
 
-            if args.rehearse_on_one_gpu:  # gloo moves host tensors; the merge still runs on the device
-                outs = allgather_merge_many([(v.cpu(), i.cpu()) for v, i in outs],
-                                            lambda v, i: tsc_hip.topk_merge(v.to(device), i.to(device)))
+            if host_collectives:  # gloo moves host tensors; the merge still runs on the device
+                outs = allgather_merge_many([(v.cpu(), i.cpu()) for v, i in outs], engine.merge)
             else:
-                outs = allgather_merge_many(outs, tsc_hip.topk_merge)
+                outs = allgather_merge_many(outs, engine.merge)
         return outs
 
     def barrier():
         if world > 1:
-            import torch.distributed as dist
-
             dist.barrier()
 
     for s in range(W):
         step(s)
     finish()
-    torch.cuda.synchronize()
+    engine.sync()
     barrier()
-    torch.cuda.synchronize()
+    engine.sync()
     t0 = time.perf_counter()
     for s in range(K):
         step(W + s, timed_index=s)
     outs = finish()
-    torch.cuda.synchronize()
+    engine.sync()
     barrier()
-    torch.cuda.synchronize()
+    engine.sync()
     elapsed = time.perf_counter() - t0
+    coll_dev = "cpu" if host_collectives else device
     if world > 1:
-        import torch.distributed as dist
-
-        t = torch.tensor([elapsed], device="cpu" if args.rehearse_on_one_gpu else device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # per-launch kernel time from the HIP events recorded on the launch stream
-    kern_ms = sum(a.elapsed_time(b) for row in ev for a, b in row)
+    kern_ms = sum(t.ms() for row in ev for t in row)
     n_launch = K * len(widths)
     flops = sum(2.0 * D_IN * d_sae * B for _, _, d_sae in widths) * K
     achieved = flops / (kern_ms * 1e-3) / 1e12
     filled = sum(int((idx[:, -1] >= 0).sum()) for _, idx in outs)
     total_feats = sum(d for _, _, d in widths)
 
+    # ---- outside the timing: are the lists right?  (the last timed batch of the narrowest and the widest
+    # dictionary against the library's own dense activations; with N > 1 every rank checks its own tokens
+    # against the MERGED lists, and every rank must hold the same lists)
+    verified = None
+    if not args.no_verify:
+        order = sorted(range(len(widths)), key=lambda i: widths[i][2])
+        last = W + K - 1
+        verified = True
+        for i in sorted({order[0], order[-1]}):
+            v, ix = outs[i]
+            verified = verified and verify_slice(engine, dicts[i], xs[last % n_batches][i], rank_base + last * B,
+                                                 v.to(device), ix.to(device))
+    identical = None
+    if world > 1:
+        h = hashlib.sha256()
+        for v, ix in outs:
+            h.update(v.cpu().numpy().tobytes())
+            h.update(ix.cpu().numpy().tobytes())
+        mine = torch.frombuffer(bytearray(h.digest()), dtype=torch.uint8).to(coll_dev)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        identical = all(bool((g == gathered[0]).all()) for g in gathered)
+        if verified is not None:
+            t = torch.tensor([1 if verified else 0], device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            verified = bool(t.item())
+
     if rank == 0:
+        traffic, traffic_src = measured_traffic()
         out = {
             "metric": "activation tokens/sec encoded + per-feature top-k (1/8 GPU); MFMA util %",
             "value": world * K * B / elapsed,
@@ -206,14 +446,17 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: 12 transcoders + 12 z-SAEs (10 x 24576, 2 x 49152), fp32, fused encode + running top-20",
+                "workload": "configs[1]: 12 transcoders + 12 z-SAEs (10 x 24576, 2 x 49152), fp32, fused encode + running top-20"
+                            if not args.dict_widths else f"test widths {args.dict_widths}",
                 "positions_per_step_per_gpu": B,
                 "dictionaries": len(widths),
                 "features_total": total_feats,
                 "k": args.k,
                 "parallelism": f"token-sharded x{world}, final all-gather + merge" if world > 1 else "single GPU",
                 "lists_full_at_end": f"{filled}/{total_feats}",
+                "engine": engine.name,
             },
+            "verified": verified,
             "dictionary_tokens_per_s": world * K * B * len(widths) / elapsed,
             "roofline": {
                 "bound": "mfma",
@@ -224,23 +467,30 @@ def main():
                 "frac": achieved / PEAK_F32_MATRIX_TFLOPS,
                 "avg_launch_ms": kern_ms / n_launch,
                 "launches": n_launch,
-                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_encode_topk_pmc_v9.json), per launch on a
-                # 24576-wide dictionary, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  These are
-                # the L2's fabric-side requests: x + W_enc^T (125 MB) stay in the 256 MiB Infinity Cache, so almost
-                # all of it is served on die; the algorithmic bytes are 126 MB per launch.
-                "traffic": PMC_FABRIC_BYTES_PER_LAUNCH,
-                "traffic_note": "bytes per launch at d_sae=24576, L2 fabric side incl. Infinity Cache hits (offline PMC pass); "
-                                "algorithmic 1.26e8",
+                # per launch, from the tracked rocprofv3 PMC summary named in traffic_source (never a literal here)
+                "traffic": traffic["bytes_per_launch"] if traffic else None,
+                "traffic_shape": {k: v for k, v in traffic.items() if k != "bytes_per_launch"} if traffic else None,
+                "traffic_source": traffic_src,
             },
         }
+        if world > 1:
+            out["lists_identical_on_all_ranks"] = identical
+            out["collective_backend"] = "gloo (one-GPU rehearsal)" if host_collectives else "nccl (RCCL)"
+        if world == 1 and not args.no_config4 and engine.name == "hip":
+            try:
+                from circuit_batch import bench_config4
+            except ImportError:
+                bench_config4 = None
+            if bench_config4 is not None:
+                out["config4"] = bench_config4(device)
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(16, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(args.cpu_tokens, threads)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_tokens, args.cpu_tokens_one_thread)
         print(json.dumps(out), flush=True)
     if world > 1:
-        import torch.distributed as dist
-
+        dist.barrier()
         dist.destroy_process_group()
+    if verified is False or identical is False:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

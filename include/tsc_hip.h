@@ -53,11 +53,15 @@ const char *tsc_last_error(void);
  * kernels contract the raw x and add bias', which equals the reference's
  * (x - b_dec) @ W_enc + b_enc (mlp_transcoder.py:200-212) up to fp32 rounding -- the same folding
  * the reference itself uses in get_feature_scores (autointerpretability.py:228-233).
- * Requires d_in % 4 == 0 and d_sae % 4 == 0, 16-byte aligned pointers.
+ * Requires d_in % 4 == 0, d_sae % 4 == 0 and d_out % 4 == 0, and 16-byte aligned pointers (all five).
  *
- * tsc_dict_refresh recomputes what the handle derived from the weights (bias', the bf16 copy);
- * call it after the borrowed tensors were updated in place (an optimiser step on the reference's
- * nn.Parameters keeps the pointers but changes the values).
+ * tsc_dict_refresh recomputes what the handle derived from the weights (bias', the transposed copy, the
+ * bf16 copy); call it after the borrowed tensors were updated in place (an optimiser step on the
+ * reference's nn.Parameters keeps the pointers but changes the values).
+ *
+ * Stream order: tsc_dict_create / tsc_dict_refresh ENQUEUE the derivation kernels on `stream` and
+ * return; the derived operands are ordered on that stream only.  An encode call on another stream must
+ * be ordered after it by the caller (an event, or a synchronize), like any other producer/consumer pair.
  */
 int tsc_dict_create(tsc_dict_t **out, int d_in, int d_sae, int d_out, int compute_dtype,
                     const float *W_enc, const float *b_enc, const float *b_dec,
@@ -96,12 +100,13 @@ int tsc_encode_dense_pre(const tsc_dict_t *dict, const float *x, int64_t M, floa
  * were not reset or replaced since: use it as it is".
  */
 #define TSC_TOPK_FLOOR_KEEP 1
+#define TSC_TOPK_MERGE_MAX 2048 /* n_lists * k of one merge; a state needs n_slots * k <= this */
 typedef struct {
     float *vals;   /* device */
     int64_t *idx;  /* device */
     int32_t d_sae;
     int32_t k;       /* 1..64 */
-    int32_t n_slots; /* 1..64 */
+    int32_t n_slots; /* 1..64, and n_slots * k <= TSC_TOPK_MERGE_MAX (checked on every call that takes a state) */
     int32_t flags;   /* TSC_TOPK_FLOOR_KEEP or 0 */
     float *floor;  /* device, [d_sae] scratch, or NULL */
 } tsc_topk_state_t;
@@ -153,7 +158,8 @@ int tsc_encode_sparse(const tsc_dict_t *dict, const float *x, int64_t M, int max
 
 /*
  * rows[i, :] = val[i] * W_dec[feat[i], :] for i < n.  Replaces `W_dec[idx] * vals.unsqueeze(-1)`
- * (circuit_lens.py:616, 651-653, 1220-1222).
+ * (circuit_lens.py:616, 651-653, 1220-1222).  An entry with feat[i] outside 0..d_sae-1 (the padding value -1
+ * of tsc_encode_sparse's rows) gives a zero row.
  */
 int tsc_decode_rows(const tsc_dict_t *dict, const int32_t *feat, const float *val, int64_t n,
                     float *rows, tsc_stream_t stream);

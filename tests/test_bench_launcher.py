@@ -1,0 +1,60 @@
+"""CPU tests of ``bench.py --gpus N``: with no WORLD_SIZE in the environment the command itself must start N
+rank processes (before any GPU call), run the all-gather + merge, and print one JSON line with ``n_gpus: N``;
+and it must refuse to report a smaller run as an N-GPU one.  The numerical engine is the test stand-in
+``cpu_bench_engine`` (the oracle on CPU, gloo collectives) -- the launcher, process-group, exchange and
+verification code is bench.py's own."""
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(extra, timeout=300):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env["PYTHONPATH"] = HERE + os.pathsep + env.get("PYTHONPATH", "")
+    env["MASTER_PORT"] = str(29900 + os.getpid() % 1500)
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + extra, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_gpus_2_starts_two_ranks_and_merges():
+    p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--tokens-per-step", "256", "--dict-widths", "96,160",
+              "--k", "5", "--engine-module", "cpu_bench_engine", "--no-cpu-baseline"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout  # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["lists_identical_on_all_ranks"] is True
+    assert out["verified"] is True
+    assert out["config"]["parallelism"].startswith("token-sharded x2")
+    assert out["value"] > 0 and out["scaling"] == "weak"
+
+
+def test_gpus_n_without_n_devices_is_refused():
+    """No GPU is visible in the build container: ``--gpus 2`` on the product engine must exit non-zero with a
+    clear message instead of printing a 1-GPU line."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        import pytest
+
+        pytest.skip("two GPUs are visible here")
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], timeout=120)
+    assert p.returncode != 0
+    assert "only" in p.stderr and "GPU" in p.stderr
+    assert not any(l.startswith("{") for l in p.stdout.splitlines())
+
+
+def test_world_size_must_match_gpus():
+    env_backup = dict(os.environ)
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", PYTHONPATH=HERE)
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--engine-module",
+                        "cpu_bench_engine"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+    assert dict(os.environ) == env_backup

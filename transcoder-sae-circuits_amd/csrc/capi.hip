@@ -60,7 +60,7 @@ int tsc_dict_create(tsc_dict_t **out, int d_in, int d_sae, int d_out, int comput
         return tsc_fail(TSC_ERR_UNSUPPORTED, "d_in, d_sae and d_out must be multiples of 4 (got %d, %d, %d)",
                         d_in, d_sae, d_out);
     if (!W_enc || !b_enc || !b_dec) return tsc_fail(TSC_ERR_ARG, "W_enc, b_enc and b_dec are required");
-    if (!aligned16(W_enc) || !aligned16(b_dec) || !aligned16(W_dec) || !aligned16(out_bias))
+    if (!aligned16(W_enc) || !aligned16(b_enc) || !aligned16(b_dec) || !aligned16(W_dec) || !aligned16(out_bias))
         return tsc_fail(TSC_ERR_ARG, "weight pointers must be 16-byte aligned");
     if (compute_dtype != TSC_F32 && compute_dtype != TSC_BF16)
         return tsc_fail(TSC_ERR_ARG, "unknown compute dtype %d", compute_dtype);
@@ -154,6 +154,11 @@ static int check_state(const tsc_topk_state_t *s) {
     if (s->d_sae <= 0 || s->k < 1 || s->k > 64 || s->n_slots < 1 || s->n_slots > 64)
         return tsc_fail(TSC_ERR_ARG, "top-k state out of range (d_sae %d, k %d, n_slots %d)", s->d_sae, s->k,
                         s->n_slots);
+    // the slots of a state are merged in one pass (tsc_topk_finalize): a state that could be filled but not
+    // finalized is refused on its first use, not after a whole sweep
+    if (s->n_slots * s->k > TSC_TOPK_MERGE_MAX)
+        return tsc_fail(TSC_ERR_UNSUPPORTED, "top-k state: n_slots * k = %d exceeds the %d entries per feature that "
+                        "tsc_topk_finalize merges (use fewer slots)", s->n_slots * s->k, TSC_TOPK_MERGE_MAX);
     return TSC_OK;
 }
 
@@ -235,7 +240,7 @@ int tsc_decode_rows(const tsc_dict_t *d, const int32_t *feat, const float *val, 
     if (n < 0) return tsc_fail(TSC_ERR_ARG, "negative row count");
     if (n == 0) return TSC_OK;
     if (!feat || !val || !rows || !aligned16(rows)) return tsc_fail(TSC_ERR_ARG, "bad decode_rows pointer");
-    return tsc_launch_decode_rows(d->W_dec, d->d_out, feat, val, n, rows, (hipStream_t)stream);
+    return tsc_launch_decode_rows(d->W_dec, d->d_sae, d->d_out, feat, val, n, rows, (hipStream_t)stream);
 }
 
 int tsc_decode_sparse(const tsc_dict_t *d, const int32_t *feat, const float *val, const int32_t *count,

@@ -437,7 +437,9 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
             TSC_STAMP(0)
             float thr[WNB];
 #pragma unroll
-            for (int bn = 0; bn < WNB; ++bn) thr[bn] = nok[bn] ? sm.thr[cbase + bn * 32] : __builtin_inff();
+            // columns past N: NaN fails every comparison (an infinite threshold would admit an infinite activation of
+            // the clamped copy column, and its owner would then write past the slot's lists)
+            for (int bn = 0; bn < WNB; ++bn) thr[bn] = nok[bn] ? sm.thr[cbase + bn * 32] : __builtin_nanf("");
             unsigned hot = 0;  // bit bm * WNB + bn: the block holds a candidate of this lane
 #pragma unroll
             for (int bm = 0; bm < WMB; ++bm)
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
                 if (!sm.pushed) break;
                 const int again = sm.again;
                 const int nq = tid < BN ? (sm.f_nq[tid] < QD ? sm.f_nq[tid] : QD) : 0;
-                if (nq > 0) {  // features past N never receive candidates (thr = inf)
+                if (nq > 0) {  // features past N never receive candidates (thr = NaN)
                     const int k = a.topk;
                     const long long off = ((long long)slot * a.N + n0 + tid) * k;
                     float *lv = a.tk_vals + off;

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void sparse_sort_kernel(int *feat, float *val,
 }
 
 // one wavefront per row; each lane moves float4 chunks
-__global__ __launch_bounds__(256) void decode_rows_kernel(const float *W_dec, int d_out, const int *feat,
+__global__ __launch_bounds__(256) void decode_rows_kernel(const float *W_dec, int d_sae, int d_out, const int *feat,
                                                          const float *val, long long n, float *rows) {
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -60,8 +60,12 @@ __global__ __launch_bounds__(256) void decode_rows_kernel(const float *W_dec, in
     for (long long i = wave; i < n; i += n_waves) {
         const int f = feat[i];
         const float v = val[i];
-        const f32x4 *src = (const f32x4 *)(W_dec + (long long)f * d_out);
         f32x4 *dst = (f32x4 *)(rows + i * d_out);
+        if (f < 0 || f >= d_sae) {  // the sparse emit pads its rows with feature -1: such an entry decodes to zero
+            for (int c = lane; c < chunks; c += 64) dst[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            continue;
+        }
+        const f32x4 *src = (const f32x4 *)(W_dec + (long long)f * d_out);
         for (int c = lane; c < chunks; c += 64) dst[c] = src[c] * v;
     }
 }
@@ -254,12 +258,12 @@ int tsc_launch_sparse_sort(int *feat, float *val, const int *count, long long M,
     return TSC_OK;
 }
 
-int tsc_launch_decode_rows(const float *W_dec, int d_out, const int *feat, const float *val, long long n,
+int tsc_launch_decode_rows(const float *W_dec, int d_sae, int d_out, const int *feat, const float *val, long long n,
                            float *rows, hipStream_t stream) {
     if (n <= 0) return TSC_OK;
     long long blocks = (n + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(decode_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, W_dec, d_out, feat,
+    hipLaunchKernelGGL(decode_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, W_dec, d_sae, d_out, feat,
                        val, n, rows);
     TSC_HIP_CHECK(hipGetLastError());
     return TSC_OK;

@@ -8,7 +8,7 @@
 
 namespace {
 
-constexpr int MERGE_MAX = 2048;  // n_lists * k entries staged in LDS per feature
+constexpr int MERGE_MAX = TSC_TOPK_MERGE_MAX;  // n_lists * k entries staged in LDS per feature
 
 __global__ void topk_fill_kernel(float *vals, long long *idx, long long n) {
     const long long stride = (long long)gridDim.x * blockDim.x;

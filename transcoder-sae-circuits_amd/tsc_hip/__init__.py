@@ -19,6 +19,7 @@ _lib: Optional[ctypes.CDLL] = None
 F32, BF16 = 0, 1
 MAX_ACTIVE_LIMIT = 8192
 MAX_DIRS = 8
+TOPK_MERGE_MAX = 2048              # include/tsc_hip.h: TSC_TOPK_MERGE_MAX
 
 # name -> (restype, argtypes); mirrors include/tsc_hip.h one to one
 _c = ctypes
@@ -250,6 +251,9 @@ class TopkState:
         if n_slots is None:
             n_slots = lib().tsc_topk_recommended_slots(d_sae)
         self.d_sae, self.k, self.n_slots = int(d_sae), int(k), int(n_slots)
+        if not (1 <= self.k <= 64 and 1 <= self.n_slots <= 64) or self.n_slots * self.k > TOPK_MERGE_MAX:
+            raise TscError(f"top-k state needs 1 <= k <= 64, 1 <= n_slots <= 64 and n_slots * k <= {TOPK_MERGE_MAX} "
+                           f"(got k={self.k}, n_slots={self.n_slots}): its slots are merged in one pass")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise TscError("top-k state must live on the GPU")
