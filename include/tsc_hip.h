@@ -134,6 +134,22 @@ int tsc_encode_topk(const tsc_dict_t *dict, const float *x, int64_t M, int64_t t
                     const tsc_topk_state_t *state, tsc_stream_t stream);
 
 /*
+ * tsc_encode_topk for callers that cannot allocate or carry a workspace: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (it has no native code and
+ * no allocator to avoid).  Same arithmetic, same lists bit for bit; the only difference is where the
+ * cross-slot floor scratch lives: not in state->floor (ignored, as is TSC_TOPK_FLOOR_KEEP: the floor is
+ * recomputed on every call) but in a file-scope device array of the library, 512 KiB per GPU, held until the
+ * process ends.  Limit: state->d_sae <= TSC_STATIC_FLOOR_MAX_D_SAE, larger states are refused with
+ * TSC_ERR_UNSUPPORTED.  The call makes no hipMalloc / hipFree and calls no allocating routine.  Every call on
+ * one GPU shares that GPU's array: calls that overlap on one GPU (different streams or threads) race on it --
+ * serialise them, or use tsc_encode_topk with a floor per state.  (A TSC_BF16 handle still uses the staging
+ * buffer tsc_dict_create allocated; this call allocates nothing for it either.)
+ */
+#define TSC_STATIC_FLOOR_MAX_D_SAE 131072
+int tsc_encode_topk_static(const tsc_dict_t *dict, const float *x, int64_t M, int64_t token_id_base,
+                           const tsc_topk_state_t *state, tsc_stream_t stream);
+
+/*
  * Merge n_lists list sets laid out [n_lists, d_sae, k] into out_vals/out_idx [d_sae, k], sorted
  * (value desc, token id asc), short lists padded with (0.0, -1).  n_lists * k <= 2048.
  * tsc_topk_finalize = merge of the state's slots.  tsc_topk_merge is also the step after the

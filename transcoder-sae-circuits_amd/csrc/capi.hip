@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "tsc_internal.h"
@@ -43,6 +44,34 @@ int run_encode(const tsc_dict_t *d, int mode, const EncodeArgs &a, hipStream_t s
     return tsc_launch_encode_f32(mode, a, s);
 }
 
+}  // namespace
+
+// ---- the allocation-free variant (include/tsc_hip.h: tsc_encode_topk_static) --------------------------------
+// The cross-slot floor of tsc_encode_topk normally lives in caller memory (state->floor).  Here it lives in
+// this file-scope device array.  `scratch` is a host-side stand-in for the symbol, NOT a device address: the
+// address on each GPU comes from hipGetSymbolAddress, once per device, and only that pointer is ever handed to
+// a kernel.  Every GPU the library runs on holds its own 512-KiB copy until the process ends.
+static __device__ __align__(256) float scratch[TSC_STATIC_FLOOR_MAX_D_SAE];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+float *g_scratch_ptr[MAX_DEVICES];  // per device: that device's address of `scratch`, or null until resolved
+
+int tsc_static_scratch_init(float **out) {
+    int dev = -1;
+    TSC_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return tsc_fail(TSC_ERR_UNSUPPORTED, "device ordinal %d outside 0..%d", dev, MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        float *p = nullptr;
+        TSC_HIP_CHECK(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));  // of the CURRENT device
+        if (!p) return tsc_fail(TSC_ERR_HIP, "hipGetSymbolAddress returned a null address for the static scratch");
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return TSC_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -88,6 +117,14 @@ int tsc_dict_create(tsc_dict_t **out, int d_in, int d_sae, int d_out, int comput
         if (e == hipSuccess) e = hipMalloc((void **)&d->bias_fold, (size_t)d_sae * sizeof(float));
         int rc = e == hipSuccess ? tsc_dict_refresh(d, stream)
                                  : tsc_fail(TSC_ERR_HIP, "hipMalloc of the handle's derived operands failed: %s", hipGetErrorString(e));
+        if (rc != TSC_OK) {
+            tsc_dict_destroy(d);
+            return rc;
+        }
+    }
+    {
+        float *unused = nullptr;  // set-up time: resolve this device's address of the static floor scratch
+        int rc = tsc_static_scratch_init(&unused);
         if (rc != TSC_OK) {
             tsc_dict_destroy(d);
             return rc;
@@ -193,6 +230,25 @@ int tsc_encode_topk(const tsc_dict_t *d, const float *x, int64_t M, int64_t toke
         a.tk_floor = s->floor;
     }
     return run_encode(d, TSC_MODE_TOPK, a, (hipStream_t)stream);
+}
+
+int tsc_encode_topk_static(const tsc_dict_t *d, const float *x, int64_t M, int64_t token_id_base,
+                           const tsc_topk_state_t *s, tsc_stream_t stream) {
+    int rc = check_state(s);
+    if (rc) return rc;
+    if (s->d_sae > TSC_STATIC_FLOOR_MAX_D_SAE)
+        return tsc_fail(TSC_ERR_UNSUPPORTED, "tsc_encode_topk_static holds the floor of at most %d features in its "
+                        "static scratch; this state has d_sae %d (use tsc_encode_topk with state->floor)",
+                        TSC_STATIC_FLOOR_MAX_D_SAE, s->d_sae);
+    float *floor = nullptr;
+    rc = tsc_static_scratch_init(&floor);
+    if (rc) return rc;
+    // the shared array still holds the last call's floor (possibly of another state): never keep it.  The floor
+    // kernel rewrites entries 0 .. d_sae-1, which are all this call reads, so nothing needs clearing.
+    tsc_topk_state_t t = *s;
+    t.floor = floor;
+    t.flags = s->flags & ~TSC_TOPK_FLOOR_KEEP;
+    return tsc_encode_topk(d, x, M, token_id_base, &t, stream);
 }
 
 int tsc_topk_merge(const float *vals, const int64_t *idx, int n_lists, int d_sae, int k, float *out_vals,

@@ -20,6 +20,7 @@ F32, BF16 = 0, 1
 MAX_ACTIVE_LIMIT = 8192
 MAX_DIRS = 8
 TOPK_MERGE_MAX = 2048              # include/tsc_hip.h: TSC_TOPK_MERGE_MAX
+STATIC_FLOOR_MAX_D_SAE = 131072    # include/tsc_hip.h: TSC_STATIC_FLOOR_MAX_D_SAE
 
 # name -> (restype, argtypes); mirrors include/tsc_hip.h one to one
 _c = ctypes
@@ -36,6 +37,7 @@ _SIGNATURES = {
     "tsc_set_tuning": (_c.c_int, [_c.c_char_p, _c.c_int]),
     "tsc_topk_state_reset": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "tsc_encode_topk": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
+    "tsc_encode_topk_static": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
     "tsc_topk_merge": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
                                   _c.c_void_p, _c.c_void_p]),
     "tsc_topk_finalize": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
@@ -177,6 +179,16 @@ class DeviceDict:
         with torch.cuda.device(x.device):
             _check(lib().tsc_encode_topk(self._handle, x2.data_ptr(), x2.shape[0], int(token_id_base),
                                          ctypes.byref(state._struct), _stream()))
+
+    def encode_topk_static(self, x: torch.Tensor, token_id_base: int, state: "TopkState") -> None:
+        """``tsc_encode_topk_static``: the same lists as :meth:`encode_topk`, with the cross-slot floor in the
+        library's static device scratch -- the call allocates nothing (for callers under HIP graph capture or
+        in loops that may not allocate).  ``d_sae <= STATIC_FLOOR_MAX_D_SAE``; calls that overlap on one GPU
+        race on the shared scratch."""
+        x2 = _dev(x, torch.float32, "x").reshape(-1, self.d_in)
+        with torch.cuda.device(x.device):
+            _check(lib().tsc_encode_topk_static(self._handle, x2.data_ptr(), x2.shape[0], int(token_id_base),
+                                                ctypes.byref(state._struct), _stream()))
 
     def encode_pre(self, x: torch.Tensor) -> torch.Tensor:
         """``(x - b_dec) @ W_enc + b_enc`` (no ReLU: the reference's ``hook_hidden_pre``)."""
