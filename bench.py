@@ -181,7 +181,7 @@ def cpu_baseline(tokens_all, tokens_one):
 
     from oracle.encode_ref import encode_ref
     from oracle.topk_ref import active_examples_ref, topk_stream_ref
-    from synthetic_dicts import make_dictionary_weights
+    from standins.synthetic_dicts import make_dictionary_weights
 
     model, phys = _cpu_info()
     share = min(16, os.cpu_count() or 1)  # the GPU box grants 16 CPUs per GPU whatever os.cpu_count() says
@@ -223,6 +223,87 @@ def cpu_baseline(tokens_all, tokens_one):
                   f"({main['dictionary_tokens_per_s']:.0f} dictionary-tokens/s) / the {units:.0f} such units per position",
         "legs": legs,
     }
+
+
+# ----------------------------------------------------------------------------- config 4 (side object)
+def config4_side_object(device, n_prompts=512, reps=5):
+    """BASELINE configs[3], driver-timed as a side object of the same JSON line: the CircuitLens feature-contribution
+    decomposition of ``n_prompts`` IOI-shaped prompts at the evaluation position, all 12 layers (12 transcoders + 12
+    z-SAEs at their real widths), each prompt against its own logit-difference direction, through the PRODUCT path
+    (``TaskEvaluation.contribution_decomposition`` -> ``BatchedCircuitLens.direction_lens`` -> one
+    ``tsc_sparse_lens_pass`` per dictionary).  The stand-in model's forward is upstream of the path and timed
+    separately.  Bound at 512 positions: the fp32 MFMA contraction of the sparse emit (weights are read once:
+    2 x 26 x 75.5 MB = 0.5 ms at 8 TB/s, against 3.2 ms of MFMA work at peak)."""
+    import load_model_and_encoders as lme
+    from mlp_transcoder import SparseTranscoder
+    from standins.synthetic_model import SyntheticHookedTransformer
+    from standins.synthetic_prompts import make_ioi_prompts
+    from task_evaluation import TaskEvaluation
+    from types import SimpleNamespace
+    from z_sae import ZSAE
+
+    torch.manual_seed(4)
+    prev = torch.is_grad_enabled()
+    torch.set_grad_enabled(False)
+    try:
+        model = SyntheticHookedTransformer(n_layers=12, d_vocab=8192, n_ctx=32, seed=4, device=device)
+        z_saes, tcs = [], []
+        for _, layer, d_sae in dictionary_widths()[12:]:
+            m = ZSAE({"dict_size": d_sae, "l1_coeff": 1.0, "enc_dtype": "fp32", "seed": 40 + layer, "act_size": D_IN,
+                      "device": str(device), "layer": layer})
+            z_saes.append(m)
+        for _, layer, d_sae in dictionary_widths()[:12]:
+            cfg = SimpleNamespace(d_in=D_IN, d_sae=d_sae, l1_coefficient=1e-3, dtype=torch.float32, device=str(device),
+                                  is_transcoder=True, d_out=D_IN, is_sparse_connection=False, use_ghost_grads=False,
+                                  hook_point=f"blocks.{layer}.ln2.hook_normalized", hook_point_layer=layer)
+            m = SparseTranscoder(cfg)
+            tcs.append(m)
+        lme.model_cache = model
+        lme.model_encoder_cache = (model, z_saes, tcs)
+        prompts = make_ioi_prompts(n_prompts, seed=1)
+        te = TaskEvaluation(prompts, None, no_mean_cache=True)
+        t0 = time.perf_counter()
+        batch = te.batched_lens()  # model forward over all prompts (upstream, PyTorch) -- not part of the pass
+        torch.cuda.synchronize()
+        t_forward = time.perf_counter() - t0
+        # b_enc such that ~0.26 % of the features are active per position (64 of 24576, the L0 of a trained
+        # dictionary; the same density as the main workload): 2.8 standard deviations of each dictionary's
+        # pre-activations on these very inputs
+        for enc, x in zip(*batch._encoders_and_inputs()):
+            enc.b_enc.fill_(-2.8 * float((x[:128] @ enc.W_enc).std()))
+        dirs = te.logit_difference_directions()
+        out = batch.direction_lens(dirs, k=10)  # warm-up (registers the dictionaries with the library)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(reps):
+            out = batch.direction_lens(dirs, k=10)
+        e1.record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / reps
+        t = e0.elapsed_time(e1) * 1e-3 / reps
+        counts = batch.dictionary_pass()[5]
+        n_active = int(counts.sum())
+        rows = batch.n_rows
+        widths = [w for _, _, w in dictionary_widths()]
+        flops = sum(2.0 * D_IN * w * rows for w in widths)
+        by = n_active * (D_IN * 4 + 8) + rows * 24 * D_IN * 4 * 3 + sum(2 * D_IN * w * 4 for w in widths)
+        return {
+            "workload": f"configs[3]: CircuitLens decomposition, {n_prompts} IOI-shaped prompts x eval position x 24 dictionaries, "
+                        "per-prompt logit-difference direction, top-10 components per prompt",
+            "value": rows / t, "unit": "positions/s", "ms_per_pass": t * 1e3, "ms_per_pass_wall": wall * 1e3,
+            "model_forward_ms": t_forward * 1e3,
+            "active_features_per_position_and_dictionary": n_active / rows / 24,
+            "host_syncs_per_pass": 1,
+            "roofline": {"bound": "mfma", "achieved": flops / t / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / t / 1e12 / PEAK_F32_MATRIX_TFLOPS},
+            "algorithmic_bytes_per_pass": by, "hbm_frac": by / t / 1e12 / PEAK_HBM_TBS,
+            "top1_component_of_prompt_0": out["component_names"][int(out["top_component"][0, 0])],
+        }
+    finally:
+        torch.set_grad_enabled(prev)
+        lme.clear_cache()
 
 
 # ----------------------------------------------------------------------------- traffic
@@ -477,12 +558,9 @@ def main(argv=None):
             out["lists_identical_on_all_ranks"] = identical
             out["collective_backend"] = "gloo (one-GPU rehearsal)" if host_collectives else "nccl (RCCL)"
         if world == 1 and not args.no_config4 and engine.name == "hip":
-            try:
-                from circuit_batch import bench_config4
-            except ImportError:
-                bench_config4 = None
-            if bench_config4 is not None:
-                out["config4"] = bench_config4(device)
+            del xs, dicts, states
+            torch.cuda.empty_cache()
+            out["config4"] = config4_side_object(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_tokens, args.cpu_tokens_one_thread)
         print(json.dumps(out), flush=True)

@@ -203,6 +203,24 @@ int tsc_contrib_scores(const tsc_dict_t *dict, const int32_t *feat, const float 
                        int n_dir, float *scores, tsc_stream_t stream);
 
 /*
+ * The CircuitLens decomposition of a BATCH of positions against one dictionary in two launches: the sparse emit
+ * of tsc_encode_sparse, then one kernel that, per row, orders the emitted pairs (value descending) and reads each
+ * active feature's W_dec row once for both
+ *   recon[m, :]  = out_bias + sum_i val[m,i] * W_dec[feat[m,i], :]          (as tsc_decode_sparse; NULL = skip)
+ *   scores[m, i] = val[m,i] * dot(W_dec[feat[m,i], :], dirs[m * dir_row_stride .. ])   (NULL = skip)
+ * i.e. tsc_contrib_scores with n_dir = 1 and a direction PER ROW (dir_row_stride >= d_out: every prompt has its
+ * own logit-difference direction, task_evaluation.py:141-151) or one shared direction (dir_row_stride = 0).
+ * scores has row pitch max_active; entries at i >= count[m] are 0.  Outputs feat/val/count as tsc_encode_sparse.
+ * count_is_zero != 0: the caller has already zeroed count (one memset for the counts of many dictionaries).
+ * Replaces, for all positions at once, the per-position z-SAE / transcoder forward, error terms, nonzero + topk,
+ * W_dec gather (circuit_lens.py:585-653) and the lens dot product on the feature rows (:762-766).
+ * Needs d_out <= 768 and max_active <= 2048 (else TSC_ERR_UNSUPPORTED: use the three separate calls).
+ */
+int tsc_sparse_lens_pass(const tsc_dict_t *dict, const float *x, int64_t M, int max_active, int32_t *feat,
+                         float *val, int32_t *count, int count_is_zero, const float *dirs,
+                         int64_t dir_row_stride, float *recon, float *scores, tsc_stream_t stream);
+
+/*
  * Scores of a few selected features for every token, without touching the other d_sae - F columns:
  *   out[m, j] = act( dot(x[m,:] - b_dec, Pt[j,:]) + bias[j] ),  act = ReLU if apply_relu else identity,
  * Pt [F, d_in] holds the selected encoder columns as rows (W_enc[:, feats] transposed), bias [F],

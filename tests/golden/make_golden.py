@@ -31,8 +31,8 @@ REF = "/root/reference/src"
 sys.dont_write_bytecode = True
 sys.path.insert(0, PKG)
 
-from synthetic_dicts import make_dictionary_weights, weights_fingerprint  # noqa: E402
-from synthetic_model import SyntheticHookedTransformer  # noqa: E402
+from standins.synthetic_dicts import make_dictionary_weights, weights_fingerprint  # noqa: E402
+from standins.synthetic_model import SyntheticHookedTransformer  # noqa: E402
 
 
 # ----------------------------------------------------------------------------- shims

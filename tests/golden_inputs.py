@@ -5,8 +5,8 @@ import os
 import numpy as np
 import torch
 
-from synthetic_dicts import make_dictionary_weights, weights_fingerprint
-from synthetic_model import SyntheticHookedTransformer
+from standins.synthetic_dicts import make_dictionary_weights, weights_fingerprint
+from standins.synthetic_model import SyntheticHookedTransformer
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 PROMPT = "Mary and Jeff went to the store, and Mary gave an apple to Jeff"
@@ -68,3 +68,40 @@ def lens_inputs(n_layers=3):
 
 def proj8():
     return torch.randn(768, 8, generator=torch.Generator().manual_seed(303))
+
+
+def g5_inputs():
+    """Inputs of ``g5_callers.npz`` (tests/golden/make_golden_callers.py): the g2 transcoder and activations, a
+    z-SAE on the same activations, and the IOI prompts the reference generated."""
+    import json
+
+    g5 = load("g5_callers.npz")
+    g, w, xs, n_seq, n_pos = g2_inputs()
+    wz = make_dictionary_weights(768, 1536, seed=22, b_enc=(-1.5, -3.6), transcoder=False)
+    _check(g5["fp_tc"], w)
+    _check(g5["fp_zs"], wz)
+    prompts = json.load(open(os.path.join(GOLDEN, "g5_prompts.json")))
+    return g5, w, wz, xs, n_seq, n_pos, prompts
+
+
+def same_ranking(got_pairs, got_vals, ref_pairs, ref_vals):
+    """Rankings agree when the value sequences are equal and, within every run of exactly equal values, the same
+    SET of (row) pairs appears (the reference's argsort is unstable, so the order inside a tie is unspecified)."""
+    import numpy as np
+
+    got_pairs, ref_pairs = np.asarray(got_pairs), np.asarray(ref_pairs)
+    got_vals, ref_vals = np.asarray(got_vals), np.asarray(ref_vals)
+    if got_pairs.shape != ref_pairs.shape or not np.array_equal(got_vals, ref_vals):
+        return False
+    start = 0
+    n = len(ref_vals)
+    while start < n:
+        end = start + 1
+        while end < n and ref_vals[end] == ref_vals[start]:
+            end += 1
+        a = sorted(map(tuple, got_pairs[start:end].reshape(end - start, -1).tolist()))
+        b = sorted(map(tuple, ref_pairs[start:end].reshape(end - start, -1).tolist()))
+        if a != b:
+            return False
+        start = end
+    return True

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import encode_ref as E
-from synthetic_dicts import make_dictionary_weights
+from standins.synthetic_dicts import make_dictionary_weights
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -133,3 +133,35 @@ def test_long_stream_running_topk_full_width():
     assert st._calls == n_batches
     assert torch.equal(v, exp_v), float((v - exp_v).abs().max())
     assert torch.equal(i, exp_i), int((i != exp_i).sum())
+
+
+def test_all_24_dictionaries_full_width_step_loop_is_verified():
+    """The benchmarked workload itself (BASELINE configs[1]: 12 transcoders + 12 z-SAEs at their real widths): a
+    few steps of the bench's step loop, then EVERY dictionary's lists are checked against the library's own dense
+    activations of EVERY step's batch with the bench's exact membership test (bench.verify_slice)."""
+    import bench
+
+    engine = bench.HipEngine(0, True)
+    widths = bench.dictionary_widths()
+    assert len(widths) == 24 and sum(w for _, _, w in widths) == 26 * 24576
+    B, steps = 4096, 3
+    gen = torch.Generator(device=DEV).manual_seed(99)
+    dicts, states = [], []
+    for i, (_, _, d_sae) in enumerate(widths):
+        dicts.append(engine.make_dict(*bench.make_device_dictionary(d_sae, 500 + i, DEV)))
+        states.append(engine.make_state(d_sae, 20))
+    xs = [torch.randn(len(widths), B, 768, generator=gen, device=DEV) for _ in range(steps)]
+    xs[2][:, 100:400] = xs[0][:, 100:400]  # the same contexts again: exact ties with older tokens
+    for s in range(steps):
+        for i, d in enumerate(dicts):
+            engine.encode_topk(d, xs[s][i], 7 + s * B, states[i])
+    for i, d in enumerate(dicts):
+        v, ix = engine.finalize(states[i])
+        assert bool((ix[:, -1] >= 0).all())  # 12288 tokens at 0.26 % density: every list is full
+        for s in range(steps):
+            assert bench.verify_slice(engine, d, xs[s][i], 7 + s * B, v, ix), (i, s)
+    # and the check is not vacuous: a corrupted list is caught
+    v, ix = engine.finalize(states[0])
+    v2 = v.clone()
+    v2[5, 3] = v2[5, 3] * 1.5
+    assert not bench.verify_slice(engine, dicts[0], xs[0][0], 7, v2, ix)

@@ -78,7 +78,7 @@ def test_encode_dense_ragged_rows(m):
 
 def test_encode_dense_odd_shapes():
     # d_in not a multiple of the K step, d_sae not a multiple of the column tile
-    from synthetic_dicts import make_dictionary_weights
+    from standins.synthetic_dicts import make_dictionary_weights
 
     w = make_dictionary_weights(d_in=100, d_sae=200, seed=5, b_enc=-0.1)
     d, _ = _dd(w)
@@ -94,7 +94,7 @@ def test_all_epilogues_on_ragged_dictionary_shapes(d_in, d_sae, bf16):
     column tile (clamped W rows, masked columns), the shortest k-loops of the LDS-DMA kernels
     (d_in = 64 / 128), a d_in that falls back to register staging (96), ragged token tiles."""
     import tsc_hip
-    from synthetic_dicts import make_dictionary_weights
+    from standins.synthetic_dicts import make_dictionary_weights
 
     w = make_dictionary_weights(d_in=d_in, d_sae=d_sae, seed=d_in + d_sae, b_enc=-0.2)
     d, g = _dd(w, compute_dtype=tsc_hip.BF16 if bf16 else tsc_hip.F32)
@@ -132,7 +132,7 @@ def test_every_kernel_variant_gives_the_same_results(variant):
     (``tsc_set_tuning``), each must reproduce the oracle (dense) and the exact ranking of its own dense
     activations (fused top-k, sparse emit), on a ragged shape."""
     import tsc_hip
-    from synthetic_dicts import make_dictionary_weights
+    from standins.synthetic_dicts import make_dictionary_weights
 
     bf16 = any(k.startswith("bf16") for k in variant)
     w = make_dictionary_weights(d_in=768, d_sae=1000, seed=77, b_enc=-0.9)
@@ -170,7 +170,7 @@ def test_folded_decoder_bias_under_cancellation():
     first.  Worst case for that: activations that sit close to a large b_dec, as in
     a trained dictionary whose b_dec is the mean activation -- x @ W_enc and b_dec @ W_enc then cancel to
     two digits.  The result must still meet the fp32 gate against the reference order of operations."""
-    from synthetic_dicts import make_dictionary_weights
+    from standins.synthetic_dicts import make_dictionary_weights
 
     w = make_dictionary_weights(768, 1536, seed=31, b_enc=0.0)
     gen = torch.Generator().manual_seed(32)
@@ -208,7 +208,7 @@ def test_fused_topk_descending_stream_forces_slow_path():
     """Every token beats the running k-th best (activations grow with the token id), so the
     candidate queue overflows and the multi-round drain is exercised."""
     import tsc_hip
-    from synthetic_dicts import make_dictionary_weights
+    from standins.synthetic_dicts import make_dictionary_weights
 
     w = make_dictionary_weights(768, 256, seed=3, b_enc=0.0)
     w["W_enc"] = w["W_enc"].abs()
@@ -327,7 +327,7 @@ def test_bf16_fused_topk_bit_exact_against_own_dense(k, n_slots, batch):
 def test_bf16_wide_dictionary_config5_shape():
     """d_sae = 131072 (BASELINE config 5), chunked input (more rows than the bf16 workspace holds)."""
     import tsc_hip
-    from synthetic_dicts import make_dictionary_weights
+    from standins.synthetic_dicts import make_dictionary_weights
 
     w = make_dictionary_weights(768, 131072, seed=5, b_enc=-0.35)
     d, _ = _dd(w, compute_dtype=tsc_hip.BF16)

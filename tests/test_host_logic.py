@@ -114,7 +114,7 @@ def test_sweep_checkpoint_and_resume(tmp_path):
     the file holds plain tensors only (loadable with weights_only=True)."""
     import topk_scan
     from oracle.topk_ref import topk_stream_ref
-    from synthetic_dicts import make_dictionary_weights
+    from standins.synthetic_dicts import make_dictionary_weights
 
     ws = {n: make_dictionary_weights(64, 96, seed=i, b_enc=-0.3) for i, n in enumerate(("z_0", "mlp_0"))}
     x = torch.randn(600, 64, generator=torch.Generator().manual_seed(0))

@@ -132,3 +132,78 @@ def test_lens_scores():
                 _close(sc[:, 0].numpy(), g4[f"ixg_d0_l{l}"][nz.numpy()])
         _close((L.attn_head_contribs_ref(model, cache, z_w[l], l, seq) @ proj).numpy(),
                g4[f"attn_contribs_proj_l{l}"], atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- g5: the reference's caller functions
+def test_oracle_matches_the_real_max_act_analysis_and_feature_scores():
+    from oracle import callers_ref as C
+    from replay_model import ReplayModel
+
+    g5, w, wz, xs, n_seq, n_pos, prompts = gi.g5_inputs()
+    acts = E.encode_ref(xs, w["W_enc"], w["b_enc"], w["b_dec"])
+    for f in (3, 700, 1535):
+        seq_pos, vals, _ = T.active_examples_ref(acts[:, f].reshape(n_seq, n_pos))
+        assert gi.same_ranking(seq_pos.numpy(), vals.numpy(), g5[f"maa_seq_pos_{f}"], g5[f"maa_vals_{f}"])
+        assert seq_pos.shape[0] == int(g5[f"maa_num_examples_{f}"])
+    zacts = E.encode_ref(xs, wz["W_enc"], wz["b_enc"], wz["b_dec"])
+    seq_pos, vals, _ = T.active_examples_ref(zacts[:, 11].reshape(n_seq, n_pos))
+    assert gi.same_ranking(seq_pos.numpy(), vals.numpy(), g5["maa_attn_seq_pos_11"], g5["maa_attn_vals_11"])
+    model = ReplayModel(xs, n_seq, n_pos)
+    for kind, f, ww in (("mlp", 3, w), ("mlp", 700, w), ("attn", 11, wz), ("attn", 1000, wz)):
+        _, ids = C.top_k_tokens_ref(ww, f, model.W_U, k=5, W_O_layer=model.W_O[0] if kind == "attn" else None)
+        assert ids.tolist() == g5[f"top_tokens_{kind}_{f}"].tolist()
+    post = torch.randn(768, 3, generator=torch.Generator().manual_seed(77)) * 0.05
+    for key, dec in (("gfs_post_raw", False), ("gfs_post_decoder", True)):
+        got = C.feature_scores_post_ref(xs, w, [5, 6, 7], post, n_pos, use_decoder=dec)
+        _close(got.astype(np.float32), g5[key].astype(np.float32), rtol=2e-3, atol=2e-3)
+    zs = T.feature_scores_ref(xs, wz, [11, 1000], n_pos, batch_seqs=8)
+    _close(zs.astype(np.float32), g5["gfs_zsae"].astype(np.float32), rtol=2e-3, atol=1e-4)
+    g2 = gi.load("g2_topk.npz")
+    for j, f in enumerate((3, 17, 700)):
+        sc, seq, pos = T.top_k_activating_examples_ref(g2["gfs_scores"][:, j, :], k=5)
+        ref_sc = g2["gfs_scores"][g5[f"gtk_seq_{f}"], j, g5[f"gtk_pos_{f}"]]
+        assert gi.same_ranking(np.stack([seq, pos], 1), sc, np.stack([g5[f"gtk_seq_{f}"], g5[f"gtk_pos_{f}"]], 1), ref_sc)
+        assert np.array_equal(g2["gfs_scores"][g5[f"gtk_seq_{f}"], j, :], g5[f"gtk_per_seq_{f}"])
+
+
+def test_oracle_matches_the_real_logit_difference_and_contribs():
+    from oracle import callers_ref as C
+
+    g5, w, wz, xs, n_seq, n_pos, prompts = gi.g5_inputs()
+    g3, g4, model, z_w, t_w, tokens, cache = _lens_setup()
+    assert np.array_equal(model.to_tokens([p["text"] for p in prompts]).numpy(), g5["te_tokens"])
+    for i, p in enumerate(prompts):
+        d = C.logit_difference_ref(model, p["correct"], p["counter"])
+        assert np.array_equal(d.numpy(), g5[f"te_logit_diff_{i}"])
+        assert float(d[:-1].abs().max()) == 0.0 and float(d[-1].abs().max()) > 0  # the BOS rows cancel
+    seq = 12
+    tok = int(tokens[0, seq + 1])
+    direction = model.W_U[:, tok] - model.W_U[:, int(tokens[0, 1])]
+    for l in range(3):
+        c = C.transcoder_contribs_ref(cache, t_w[l], l, seq, direction, k=5)
+        assert [x[3] for x in c] == g5[f"tc_contribs_idx_l{l}"].tolist()
+        _close(np.array([x[4] for x in c]), g5[f"tc_contribs_val_l{l}"])
+    top = C.top_contribs_ref(cache, t_w, 2, seq, direction, k=5)
+    assert [[x[1], x[3]] for x in top] == g5["top_contribs_layer_idx"].tolist()
+    _close(np.array([x[4] for x in top]), g5["top_contribs_val"])
+    _close((torch.stack([x[0] for x in top]) @ gi.proj8()).numpy(), g5["top_contribs_vec_proj"], atol=1e-4)
+
+
+def test_oracle_lens_rankings_not_cut_by_the_embed_break():
+    from circuit_lens import ActiveFeatures
+
+    g5, *_ = gi.g5_inputs()
+    g3, g4, model, z_w, t_w, tokens, cache = _lens_setup()
+    s2, tok = g5["unembed2_seq_tok"].tolist()
+    vectors, values, features, keys = L.active_features_ref(model, cache, z_w, t_w, s2)
+    af = ActiveFeatures(vectors=vectors, values=values, features=features, keys=keys)
+    top = af.get_top_k_features(L.normalize_ref(L.unembed_lens_raw_ref(vectors, model.W_U, tok)), k=10)
+    assert len(top) == 10
+    assert [[gi.COMPONENT_IDS.index(c), l, f] for c, l, f, _ in top] == g5["unembed2_top_ids"].tolist()
+    _close(np.array([v for *_, v in top]), g5["unembed2_top_vals"], atol=1e-5)
+    layer, s3, feat = g5["mlp_lens2_layer_seq_feature"].tolist()
+    vectors, values, features, keys = L.active_features_ref(model, cache, z_w, t_w, s3)
+    af = ActiveFeatures(vectors=vectors, values=values, features=features, keys=keys)
+    top = af.get_top_k_features(L.normalize_ref(L.mlp_feature_lens_raw_ref(vectors, keys, t_w, layer, feat)), k=10)
+    assert [[gi.COMPONENT_IDS.index(c), l, f] for c, l, f, _ in top] == g5["mlp_lens2_top_ids"].tolist()
+    _close(np.array([v for *_, v in top]), g5["mlp_lens2_top_vals"], atol=1e-5)

@@ -21,7 +21,7 @@ def _dict(w):
 
 def test_static_scratch_entry_point_matches_encode_topk():
     import tsc_hip
-    from synthetic_dicts import make_dictionary_weights
+    from standins.synthetic_dicts import make_dictionary_weights
 
     g, w, xs, n_seq, n_pos = gi.g2_inputs()            # d_sae 1536
     wide = make_dictionary_weights(768, 24576, seed=9, b_enc=-0.7)  # a second state of another width on the same scratch

@@ -18,7 +18,7 @@ def get_feature_scores(model, encoder, tokens_arr, feature_indices, batch_size=6
                        use_raw_scores=False, use_decoder=False, feature_post=None, ignore_endoftext=False):
     if isinstance(encoder, ZSAE):
         act_name = act_name or "attn.hook_z"
-        layer = encoder.cfg["layer"]
+        layer = encoder.cfg["layer"]  # the reference reads the layer from the cfg too (:203)
         name_filter = f"blocks.{layer}.attn.hook_z"
     elif isinstance(encoder, SparseTranscoder):
         act_name = act_name or encoder.cfg.hook_point
@@ -58,11 +58,15 @@ def get_feature_scores(model, encoder, tokens_arr, feature_indices, batch_size=6
                 mask = torch.as_tensor([t == eos for t in cur_tokens.reshape(-1).tolist()], device=cur.device)
                 cur[mask] = -torch.inf
         n_pos = tokens_arr.shape[1]
-        cur = cur.reshape(-1, n_pos, cur.shape[-1]).permute(0, 2, 1)  # "(b pos) n -> b n pos"
-        scores.append(cur.cpu().numpy().astype(np.float16))
+        # "(b pos) n -> b n pos", rounded to fp16 on the device (the reference's .astype(np.float16), :249-255,
+        # is the same IEEE round-to-nearest-even); batches stay on the GPU: ONE transfer at the end of the scan
+        # instead of the reference's device->host sync per batch
+        scores.append(cur.reshape(-1, n_pos, cur.shape[-1]).permute(0, 2, 1).to(torch.float16))
     if post_projector is not None:
         post_projector.close()
-    return np.concatenate(scores, axis=0)
+    if not scores:
+        return np.zeros((0, feats.numel(), tokens_arr.shape[1]), np.float16)
+    return torch.cat(scores, dim=0).cpu().numpy()
 
 
 def get_top_k_activating_examples(feature_scores, tokens, model, k=5):

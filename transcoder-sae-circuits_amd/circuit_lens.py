@@ -12,6 +12,13 @@ Drop-in for the hot-path part of reference ``src/circuit_lens.py`` (SURVEY.md se
 * contribution scores of the form ``feature_act x W_dec row . direction`` go through
   ``tsc_contrib_scores`` on the sparse active set (``contribution_scores``, ``get_transcoder_ixg``).
 
+* the reference refuses more than one prompt (:538-539).  ``BatchedCircuitLens`` lifts that: ONE model forward
+  over all prompts, ONE ``tsc_sparse_lens_pass`` per dictionary over all prompts x positions (or one chosen
+  position per prompt), one host sync for the whole pass; ``.lens(i)`` hands out per-prompt ``CircuitLens`` views
+  whose results equal those of a single-prompt ``CircuitLens`` (what ``CircuitDiscovery`` consumes), and
+  ``.direction_lens`` is the batched form of the unembed / logit-difference lens (SURVEY.md section 8f-1,
+  BASELINE config 4).
+
 Plotly heat maps are out of scope: ``visualize=True`` prints the ranked labels only.
 """
 from __future__ import annotations
@@ -259,21 +266,76 @@ class ComponentLens:
         return [], None
 
 
+class _PromptCacheView:
+    """One prompt's slice of a batched activation cache, with the batch axis kept (size 1) and the padding
+    positions cut off, so that every ``cache[...][0, pos]`` of the single-prompt code reads the same numbers."""
+
+    def __init__(self, cache, index: int, length: int):
+        self._cache, self._i, self._n = cache, index, length
+
+    def __getitem__(self, key):
+        t = self._cache[key]
+        name = key if isinstance(key, str) else key[0]
+        if name in ("pattern", "attn_scores") or (isinstance(name, str) and name.endswith(("hook_pattern", "hook_attn_scores"))):
+            return t[self._i:self._i + 1, :, :self._n, :self._n]
+        return t[self._i:self._i + 1, :self._n]
+
+
+def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want_recon: bool = True):
+    """All dictionaries of ``encoders`` (a list) over their ``inputs`` (a list of ``[R, d_in]`` tensors, the
+    same R for all) with ONE host synchronisation: the counts of every dictionary live in one tensor that is
+    zeroed once, checked against the capacity once and copied to the host once.  ``dirs``: optional list of
+    per-dictionary direction tensors (``[R, d_out]`` or ``[d_out]``) for the fused contribution scores.
+    Returns ``(feat [D,R,cap], val [D,R,cap], count [D,R], recon list, scores list, counts on host [D,R])``."""
+    import tsc_hip
+
+    n_d = len(encoders)
+    rows = inputs[0].shape[0]
+    dev = inputs[0].device
+    cap = max(1, min(int(max_active), tsc_hip.LENS_PASS_MAX_ACTIVE))
+    while True:
+        feat = torch.empty(n_d, rows, cap, dtype=torch.int32, device=dev)
+        val = torch.empty(n_d, rows, cap, dtype=torch.float32, device=dev)
+        count = torch.zeros(n_d, rows, dtype=torch.int32, device=dev)
+        recons, scores = [], []
+        for i, (enc, x) in enumerate(zip(encoders, inputs)):
+            _, _, _, r, sc = enc.device_dict().sparse_lens_pass(
+                x, cap, dirs=None if dirs is None else dirs[i], want_recon=want_recon,
+                out={"feat": feat[i], "val": val[i], "count": count[i]})
+            recons.append(r)
+            scores.append(sc)
+        counts_host = count.cpu()  # the one synchronisation of the pass
+        worst = int(counts_host.max()) if counts_host.numel() else 0
+        if worst <= cap:
+            return feat, val, count, recons, scores, counts_host
+        if cap >= tsc_hip.LENS_PASS_MAX_ACTIVE:
+            raise tsc_hip.TscError(f"a position has {worst} active features in one dictionary, above the "
+                                   f"{tsc_hip.LENS_PASS_MAX_ACTIVE} the fused lens pass holds")
+        cap = min(tsc_hip.LENS_PASS_MAX_ACTIVE, max(2 * cap, worst))
+
+
 class CircuitLens:
-    def __init__(self, prompt):
+    def __init__(self, prompt, _batch: Optional["BatchedCircuitLens"] = None, _index: int = 0):
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         model, z_saes, mlp_transcoders = get_model_encoders(self.device)
         self.z_saes = z_saes
         self.mlp_transcoders = mlp_transcoders
         self.model = model
         self.prompt = prompt
-        self.tokens = self.model.to_tokens(prompt)
-        if self.tokens.size(0) != 1:
-            raise ValueError("Can only do CircuitLens on a single prompt!")
-        with torch.no_grad():
-            self.logits, self.cache = self.model.run_with_cache(self.tokens, return_type="logits")
+        self._batch, self._index = _batch, _index
+        if _batch is not None:  # a per-prompt view of a batched pass (BatchedCircuitLens.lens)
+            n = _batch.lengths[_index]
+            self.tokens = _batch.tokens[_index:_index + 1, :n]
+            self.logits = _batch.logits[_index:_index + 1, :n]
+            self.cache = _PromptCacheView(_batch.cache, _index, n)
+        else:
+            self.tokens = self.model.to_tokens(prompt)
+            if self.tokens.size(0) != 1:
+                raise ValueError("Can only do CircuitLens on a single prompt!")  # many prompts: BatchedCircuitLens
+            with torch.no_grad():
+                self.logits, self.cache = self.model.run_with_cache(self.tokens, return_type="logits")
         self._seq_activations: Dict[int, ActiveFeatures] = {}
-        self._layer_sparse: Dict[Tuple[str, int], Tuple[torch.Tensor, ...]] = {}
+        self._pass = None  # (feat, val, count, recons, counts on host), rows = positions of this prompt
 
     @property
     def n_tokens(self):
@@ -294,23 +356,45 @@ class CircuitLens:
             return z.reshape(z.shape[0], -1).contiguous()           # "n_heads d_head -> (n_heads d_head)" per position
         return self.cache["normalized", layer, "ln2"][0].contiguous()
 
+    def _dict_index(self, kind: str, layer: int) -> int:
+        return 2 * layer + (0 if kind == "attn" else 1)
+
+    def _ensure_pass(self):
+        """All 2 x n_layers dictionaries over all positions of the prompt, one host sync in total."""
+        if self._pass is None:
+            if self._batch is not None:
+                self._pass = self._batch._pass_for_prompt(self._index)
+            else:
+                encs, xs = [], []
+                for layer in range(self.model.cfg.n_layers):
+                    encs += [self.z_saes[layer], self.mlp_transcoders[layer]]
+                    xs += [self._dictionary_input("attn", layer), self._dictionary_input("mlp", layer)]
+                with torch.no_grad():
+                    feat, val, count, recons, _, counts_host = run_dictionary_pass(encs, xs)
+                self._pass = (feat, val, count, recons, counts_host.tolist(), None)
+        return self._pass
+
     def _sparse(self, kind: str, layer: int):
-        """``(feat [n,cap], val [n,cap], count [n], recon [n,d], counts on host)`` for ALL positions."""
-        key = (kind, layer)
-        hit = self._layer_sparse.get(key)
-        if hit is None:
-            enc = self.z_saes[layer] if kind == "attn" else self.mlp_transcoders[layer]
-            with torch.no_grad():
-                feat, val, count = enc.encode_sparse(self._dictionary_input(kind, layer))
-                recon = enc.device_dict().decode_sparse(feat, val, count)
-            hit = (feat, val, count, recon, count.tolist())
-            self._layer_sparse[key] = hit
-        return hit
+        """``(feat [n,cap], val [n,cap], count [n], recon [n,d], counts on host)`` for the positions covered."""
+        feat, val, count, recons, counts, _ = self._ensure_pass()
+        i = self._dict_index(kind, layer)
+        return feat[i], val[i], count[i], recons[i], counts[i]
+
+    def _row(self, seq_index: int) -> int:
+        rows = self._ensure_pass()[5]
+        if rows is None:
+            return seq_index
+        r = rows.get(seq_index)
+        if r is None:
+            raise ValueError(f"position {seq_index} is not covered by the batched pass this view belongs to "
+                             "(build the BatchedCircuitLens with positions='all')")
+        return r
 
     def _active(self, kind: str, layer: int, seq_index: int):
         feat, val, _, recon, counts = self._sparse(kind, layer)
-        c = counts[seq_index]
-        return feat[seq_index, :c], val[seq_index, :c], recon[seq_index]
+        r = self._row(seq_index)
+        c = counts[r]
+        return feat[r, :c], val[r, :c], recon[r]
 
     def _w_o_flat(self, layer: int) -> torch.Tensor:
         w = self.model.W_O[layer]
@@ -361,7 +445,7 @@ class CircuitLens:
         if kind == "attn":
             dirs = dirs @ self._w_o_flat(layer).t()
         if seq_index is not None:
-            s = self.process_seq_index(seq_index)
+            s = self._row(self.process_seq_index(seq_index))
             feat, val, count = feat[s:s + 1].contiguous(), val[s:s + 1].contiguous(), count[s:s + 1].contiguous()
         return feat, enc.device_dict().contrib_scores(feat, val, count, dirs.contiguous()), count
 
@@ -392,6 +476,13 @@ class CircuitLens:
         return self.get_next_lens_runs(af, activations, seq_index,
                                        title=f"Unembed Lens for token '{self.model.tokenizer.decode([token_i])}'/{token_i}",
                                        visualize=visualize, k=k)
+
+    def get_direction_lens(self, direction: torch.Tensor, seq_index: int, visualize=True, k=None):
+        """``get_unembed_lens`` for an arbitrary residual direction (e.g. ``TaskEvaluation.logit_difference``)."""
+        seq_index = self.process_seq_index(seq_index)
+        af = self.get_active_features(seq_index)
+        activations = self.normalize_activations(af.vectors @ direction.to(af.vectors.device, af.vectors.dtype).reshape(-1))
+        return self.get_next_lens_runs(af, activations, seq_index, title="Direction Lens", visualize=visualize, k=k)
 
     def get_head_seq_activations_for_vector(self, layer: int, seq_index: int, vector: torch.Tensor):
         """Contribution of every (head, source position) to ``vector`` read from z at ``seq_index``:
@@ -503,9 +594,9 @@ class CircuitLens:
         pulled[feat[0, :c].long()] = scores[0, :c, 0]
         if not return_feature_activs:
             return pulled
-        f_all, v_all, _, _, counts = self._sparse("mlp", layer)
+        mf, mv, _ = self._active("mlp", layer, seq_index)
         acts = torch.zeros(d_sae, device=scores.device)
-        acts[f_all[seq_index, :counts[seq_index]].long()] = v_all[seq_index, :counts[seq_index]]
+        acts[mf.long()] = mv
         return pulled, acts
 
     def get_ln_constant(self, vector, layer, token, is_ln2=False, recip=False):
@@ -549,3 +640,193 @@ class CircuitLens:
         scores = torch.tensor([c[4] for c in contribs])
         _, top = torch.topk(scores, k=min(k, len(scores)))
         return [contribs[i.item()] for i in top]
+
+
+# ---------------------------------------------------------------------- many prompts at once
+_COMPONENT_ORDER = [CircuitComponent.EMBED, CircuitComponent.POS_EMBED, CircuitComponent.BIAS_O,
+                    CircuitComponent.Z_SAE_ERROR, CircuitComponent.Z_SAE_BIAS, CircuitComponent.Z_FEATURE,
+                    CircuitComponent.TRANSCODER_ERROR, CircuitComponent.TRANSCODER_BIAS, CircuitComponent.MLP_FEATURE]
+
+
+class BatchedCircuitLens:
+    """CircuitLens over MANY prompts (the reference stops at one, circuit_lens.py:538-539).
+
+    One ``run_with_cache`` over the padded token matrix, then ONE ``tsc_sparse_lens_pass`` per dictionary over all
+    covered rows -- every real position of every prompt (``positions="all"``) or one position per prompt
+    (``positions=-1``: the IOI evaluation position, task_evaluation.py:116) -- and one host sync for the pass.
+
+    * ``lens(i)`` -> a ``CircuitLens`` for prompt ``i`` that shares this pass: same methods, same results as
+      ``CircuitLens(prompts[i])`` (padding sits to the right of a causal model, so real positions are unaffected).
+    * ``direction_lens(directions)`` -> for every covered row the contribution of every component row of
+      ``ActiveFeatures`` to the row's direction, normalised as ``normalize_activations`` does, and its top-k --
+      ``feature_act x W_dec row . direction`` fused into the pass (no ``[comp, 768]`` matrix is built)."""
+
+    def __init__(self, prompts, positions: Union[str, int] = "all", max_active: int = 512):
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        model, z_saes, mlp_transcoders = get_model_encoders(self.device)
+        self.model, self.z_saes, self.mlp_transcoders = model, z_saes, mlp_transcoders
+        self.prompts = [prompts] if isinstance(prompts, str) else list(prompts)
+        if not self.prompts:
+            raise ValueError("BatchedCircuitLens needs at least one prompt")
+        self.lengths = [int(model.to_tokens(p).shape[1]) for p in self.prompts]
+        self.tokens = model.to_tokens(self.prompts)
+        self.max_active = max_active
+        with torch.no_grad():
+            self.logits, self.cache = model.run_with_cache(self.tokens, return_type="logits")
+        self.positions = positions
+        rp, rs, self._row_start = [], [], []
+        for i, n in enumerate(self.lengths):
+            self._row_start.append(len(rp))
+            cover = range(n) if positions == "all" else [int(positions) % n]
+            rp += [i] * len(cover)
+            rs += list(cover)
+        dev = self.tokens.device
+        self.row_prompt = torch.tensor(rp, device=dev)
+        self.row_pos = torch.tensor(rs, device=dev)
+        self._row_pos_host = rs
+        self._pass = None
+        self._views: Dict[int, CircuitLens] = {}
+
+    @property
+    def n_prompts(self):
+        return len(self.prompts)
+
+    @property
+    def n_rows(self):
+        return len(self._row_pos_host)
+
+    def _rows_of(self, key):
+        """``cache[key]`` at the covered rows -> ``[R, ...]``."""
+        return self.cache[key][self.row_prompt, self.row_pos]
+
+    def _w_o_flat(self, layer: int) -> torch.Tensor:
+        w = self.model.W_O[layer]
+        return w.reshape(w.shape[0] * w.shape[1], w.shape[2])
+
+    def _encoders_and_inputs(self):
+        encs, xs = [], []
+        for layer in range(self.model.cfg.n_layers):
+            z = self._rows_of(("z", layer))
+            encs += [self.z_saes[layer], self.mlp_transcoders[layer]]
+            xs += [z.reshape(z.shape[0], -1).contiguous(), self._rows_of(("normalized", layer, "ln2")).contiguous()]
+        return encs, xs
+
+    def dictionary_pass(self, directions: Optional[torch.Tensor] = None):
+        """Run (or return the cached) pass.  With ``directions`` (``[R, d_model]``, ``[n_prompts, d_model]`` with
+        one row per prompt, or ``[d_model]``) the contribution scores are computed in the same launches; the
+        attention dictionaries get ``directions @ W_O[layer]^T`` (the W_O projection of circuit_lens.py:618-627
+        folded into the direction)."""
+        if directions is None and self._pass is not None:
+            return self._pass
+        encs, xs = self._encoders_and_inputs()
+        dirs = None
+        if directions is not None:
+            d = self._row_directions(directions)
+            dirs = []
+            for layer in range(self.model.cfg.n_layers):
+                dirs += [(d @ self._w_o_flat(layer).t()).contiguous(), d]
+        with torch.no_grad():
+            out = run_dictionary_pass(encs, xs, self.max_active, dirs=dirs)
+        if self._pass is None or directions is None:
+            self._pass = out
+        return out
+
+    def _row_directions(self, directions: torch.Tensor) -> torch.Tensor:
+        d = directions.to(self.tokens.device, torch.float32)
+        if d.dim() == 1:
+            d = d.expand(self.n_rows, -1)
+        elif d.shape[0] == self.n_prompts and self.n_rows != self.n_prompts:
+            d = d[self.row_prompt]
+        elif d.shape[0] != self.n_rows:
+            raise ValueError(f"directions must have {self.n_rows} rows (one per covered position), "
+                             f"{self.n_prompts} (one per prompt) or be a single vector; got {tuple(d.shape)}")
+        return d.contiguous()
+
+    def _pass_for_prompt(self, index: int):
+        feat, val, count, recons, _, counts_host = self.dictionary_pass()
+        a = self._row_start[index]
+        b = self._row_start[index + 1] if index + 1 < self.n_prompts else self.n_rows
+        rowmap = None if self.positions == "all" else {self._row_pos_host[a]: 0}
+        return (feat[:, a:b], val[:, a:b], count[:, a:b], [r[a:b] for r in recons], counts_host[:, a:b].tolist(), rowmap)
+
+    def lens(self, index: int) -> CircuitLens:
+        if index not in self._views:
+            self._views[index] = CircuitLens(self.prompts[index], _batch=self, _index=index)
+        return self._views[index]
+
+    def __len__(self):
+        return self.n_prompts
+
+    def __getitem__(self, index: int) -> CircuitLens:
+        return self.lens(index)
+
+    # ------------------------------------------------------------------ batched direction lens
+    def direction_lens(self, directions: torch.Tensor, k: int = 10):
+        """For every covered row: ``normalize_activations(vectors @ direction)`` of its ``ActiveFeatures`` without
+        building the vectors, and its top-``k``.  Returns a dict of device tensors:
+
+        ``activations [R, W]`` (padded column layout, 0 in padding), ``mask [R, W]``, ``top_values [R, k]`` and the
+        identity of each winner ``top_component [R, k]`` (index into ``component_names``), ``top_layer [R, k]``,
+        ``top_feature [R, k]`` (-1 on auxiliary rows); ``-inf`` / -1 where a row has fewer than k components.
+        Column layout per row = the ActiveFeatures row order with every feature block padded to the capacity."""
+        feat, val, count, recons, scores, _ = self.dictionary_pass(directions)
+        d = self._row_directions(directions)
+        n_layers, cap, rows = self.model.cfg.n_layers, feat.shape[2], self.n_rows
+        dev = d.device
+        cols = [(self._rows_of("embed") * d).sum(-1, keepdim=True), (self._rows_of("pos_embed") * d).sum(-1, keepdim=True)]
+        slot = torch.arange(cap, device=dev)
+        masks = [torch.ones(rows, 2, dtype=torch.bool, device=dev)]
+        comp = [0, 1]
+        lay = [0, 0]
+        fcols = [torch.full((rows, 2), -1, dtype=torch.int64, device=dev)]
+        ones3 = torch.ones(rows, 3, dtype=torch.bool, device=dev)
+        minus = lambda n: torch.full((rows, n), -1, dtype=torch.int64, device=dev)  # noqa: E731
+        for layer in range(n_layers):
+            zi, mi = 2 * layer, 2 * layer + 1
+            dz = d @ self._w_o_flat(layer).t()
+            z = self._rows_of(("z", layer)).reshape(rows, -1)
+            cols += [(self.model.b_O[layer] * d).sum(-1, keepdim=True), ((z - recons[zi]) * dz).sum(-1, keepdim=True),
+                     (self.z_saes[layer].b_dec * dz).sum(-1, keepdim=True), scores[zi],
+                     ((self._rows_of(("mlp_out", layer)) - recons[mi]) * d).sum(-1, keepdim=True),
+                     (self.mlp_transcoders[layer].b_dec_out * d).sum(-1, keepdim=True), scores[mi]]
+            masks += [ones3, slot[None, :] < count[zi][:, None], ones3[:, :2], slot[None, :] < count[mi][:, None]]
+            comp += [2, 3, 4] + [5] * cap + [6, 7] + [8] * cap
+            lay += [layer] * (5 + 2 * cap)
+            fcols += [minus(3), feat[zi].long(), minus(2), feat[mi].long()]
+        raw = torch.cat(cols, dim=1)
+        mask = torch.cat(masks, dim=1)
+        raw = torch.where(mask, raw, torch.zeros_like(raw))
+        acts = raw / raw.sum(dim=1, keepdim=True)                     # normalize_activations (:551-554)
+        ranked = torch.where(mask, acts, torch.full_like(acts, float("-inf")))
+        kk = min(k, ranked.shape[1])
+        top_v, top_c = ranked.topk(kk, dim=1)
+        comp_t = torch.tensor(comp, device=dev)
+        lay_t = torch.tensor(lay, device=dev)
+        live = torch.isfinite(top_v)
+        return {
+            "activations": acts, "mask": mask, "raw": raw, "top_values": top_v,
+            "top_component": torch.where(live, comp_t[top_c], torch.full_like(top_c, -1)),
+            "top_layer": torch.where(live, lay_t[top_c], torch.full_like(top_c, -1)),
+            "top_feature": torch.where(live, torch.gather(torch.cat(fcols, dim=1), 1, top_c), torch.full_like(top_c, -1)),
+            "component_names": list(_COMPONENT_ORDER),
+            "row_prompt": self.row_prompt, "row_pos": self.row_pos,
+        }
+
+    def direction_lens_runs(self, directions: torch.Tensor, k: int = 10) -> List[List[ComponentLensWithValue]]:
+        """``direction_lens`` as the per-prompt lists the reference's lens functions return (one list per covered
+        row): ``[(ComponentLens, value)]``, ending at the first embed / pos_embed row like ``get_top_k_features``."""
+        res = self.direction_lens(directions, k=k)
+        tv, tc, tl, tf = (res[n].tolist() for n in ("top_values", "top_component", "top_layer", "top_feature"))
+        out = []
+        for r in range(self.n_rows):
+            lens = self.lens(int(self.row_prompt[r]))
+            runs = []
+            for v, c, l, f in zip(tv[r], tc[r], tl[r], tf[r]):
+                if c < 0:
+                    break
+                runs.append((ComponentLens(circuit_lens=lens, component=_COMPONENT_ORDER[c],
+                                           run_data={"layer": l, "seq_index": self._row_pos_host[r], "feature": f}), v))
+                if c < 2:
+                    break
+            out.append(runs)
+        return out

@@ -289,6 +289,31 @@ static int check_decoder(const tsc_dict_t *d) {
     return TSC_OK;
 }
 
+int tsc_sparse_lens_pass(const tsc_dict_t *d, const float *x, int64_t M, int max_active, int32_t *feat, float *val,
+                         int32_t *count, int count_is_zero, const float *dirs, int64_t dir_row_stride, float *recon,
+                         float *scores, tsc_stream_t stream) {
+    int rc = check_dict_x(d, x, M);
+    if (rc) return rc;
+    rc = check_decoder(d);
+    if (rc) return rc;
+    if (M == 0) return TSC_OK;
+    if (!feat || !val || !count) return tsc_fail(TSC_ERR_ARG, "null sparse output pointer");
+    if (scores && (!dirs || !aligned16(dirs) || (dir_row_stride != 0 && (dir_row_stride < d->d_out || (dir_row_stride & 3)))))
+        return tsc_fail(TSC_ERR_ARG, "scores need 16-byte aligned directions with row stride 0 or >= d_out (multiple of 4)");
+    if (recon && !aligned16(recon)) return tsc_fail(TSC_ERR_ARG, "recon must be 16-byte aligned");
+    if (max_active < 1 || !tsc_sparse_finish_supported(d->d_out, max_active))
+        return tsc_fail(TSC_ERR_UNSUPPORTED, "tsc_sparse_lens_pass needs d_out <= 768 and 1 <= max_active <= 2048 (got %d, %d); "
+                        "use tsc_encode_sparse + tsc_decode_sparse + tsc_contrib_scores", d->d_out, max_active);
+    hipStream_t s = (hipStream_t)stream;
+    if (!count_is_zero) TSC_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)M * sizeof(int32_t), s));
+    EncodeArgs a = base_args(d, x, M);
+    a.sp_feat = feat; a.sp_val = val; a.sp_count = count; a.max_active = max_active;
+    rc = run_encode(d, TSC_MODE_SPARSE, a, s);
+    if (rc) return rc;
+    return tsc_launch_sparse_finish(d->W_dec, d->out_bias, d->d_out, feat, val, count, M, max_active, dirs,
+                                    dir_row_stride, recon, scores, s);
+}
+
 int tsc_decode_rows(const tsc_dict_t *d, const int32_t *feat, const float *val, int64_t n, float *rows,
                     tsc_stream_t stream) {
     int rc = check_decoder(d);

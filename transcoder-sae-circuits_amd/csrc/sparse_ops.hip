@@ -190,6 +190,122 @@ __global__ __launch_bounds__(256) void contrib_kernel(const float *W_dec, int d_
     }
 }
 
+// The CircuitLens pass for a batch of positions after the sparse emit, ONE launch per dictionary: per token,
+// order the emitted (feature, value) pairs (as sparse_sort_kernel), then read each active feature's W_dec row
+// ONCE and use it twice: for the reconstruction (as decode_sparse_kernel) and for the score against the token's
+// own direction (as contrib_kernel<1>, same per-lane arithmetic and reduction order, so the scores are bit-identical
+// to tsc_contrib_scores).  grid = M, block = 256: 16 quarter waves, each takes the entries e = q, q + 16, ...
+constexpr int FIN_MAX_ACTIVE = 2048;  // sorted entries staged in LDS
+constexpr int FIN_CPL = 12;           // float4 chunks of a W_dec row per lane of a quarter wave: d_out <= 768
+__global__ __launch_bounds__(256) void sparse_finish_kernel(const float *W_dec, const float *bias, int d_out, int *feat,
+                                                           float *val, const int *count, int max_active,
+                                                           const float *dirs, long long dir_stride, float *recon,
+                                                           float *scores) {
+    __shared__ float sv[FIN_MAX_ACTIVE];
+    __shared__ int sf[FIN_MAX_ACTIVE];
+    __shared__ f32x4 sd[FIN_CPL * 16];        // the token's direction
+    __shared__ f32x4 red[4][FIN_CPL * 16];    // per-wave partial reconstructions
+    const long long m = blockIdx.x;
+    const int tid = threadIdx.x;
+    int c = count[m];
+    if (c > max_active) c = max_active;
+    int *frow = feat + m * max_active;
+    float *vrow = val + m * max_active;
+    const int chunks = d_out >> 2;
+    for (int e = tid; e < c; e += 256) {
+        sv[e] = vrow[e];
+        sf[e] = frow[e];
+    }
+    if (scores)
+        for (int i = tid; i < chunks; i += 256) sd[i] = ((const f32x4 *)(dirs + m * dir_stride))[i];
+    __syncthreads();
+    // rank sort (value descending, feature id ascending); a thread holds its entries' ranks across the barrier
+    constexpr int EPT = FIN_MAX_ACTIVE / 256;
+    float ev[EPT];
+    int ef[EPT], er[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int e = tid + 256 * j;
+        ev[j] = 0.f; ef[j] = 0; er[j] = -1;
+        if (e < c) {
+            const float v = sv[e];
+            const int f = sf[e];
+            int rank = 0;
+            for (int i = 0; i < c; ++i) {
+                const float w = sv[i];
+                rank += (w > v || (w == v && sf[i] < f)) ? 1 : 0;
+            }
+            ev[j] = v; ef[j] = f; er[j] = rank;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+        if (er[j] >= 0) {
+            sv[er[j]] = ev[j]; sf[er[j]] = ef[j];
+            vrow[er[j]] = ev[j]; frow[er[j]] = ef[j];
+        }
+    for (int e = c + tid; e < max_active; e += 256) {  // defined tail, as sparse_sort_kernel
+        vrow[e] = 0.f;
+        frow[e] = -1;
+    }
+    __syncthreads();
+    const int l16 = tid & 15, grp = tid >> 4;
+    f32x4 acc[FIN_CPL];
+#pragma unroll
+    for (int j = 0; j < FIN_CPL; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int e = grp; e < c; e += 16) {
+        const float v = sv[e];
+        const f32x4 *src = (const f32x4 *)(W_dec + (long long)sf[e] * d_out);
+        f32x4 w[FIN_CPL];
+#pragma unroll
+        for (int j = 0; j < FIN_CPL; ++j) {
+            const int ch = l16 + 16 * j;
+            w[j] = ch < chunks ? src[ch] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (scores) {
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < FIN_CPL; ++j) {
+                const int ch = l16 + 16 * j;
+                if (ch < chunks) {
+                    const f32x4 q = sd[ch];
+                    part += w[j].x * q.x + w[j].y * q.y + w[j].z * q.z + w[j].w * q.w;
+                }
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (l16 == 0) scores[m * max_active + e] = part * v;
+        }
+#pragma unroll
+        for (int j = 0; j < FIN_CPL; ++j) acc[j] += w[j] * v;
+    }
+    if (scores)
+        for (int e = c + tid; e < max_active; e += 256) scores[m * max_active + e] = 0.f;
+    if (recon) {
+        // quarter waves of one wave -> lanes 0..15; waves -> LDS; fixed order, so the result is reproducible
+#pragma unroll
+        for (int j = 0; j < FIN_CPL; ++j) {
+#pragma unroll
+            for (int comp = 0; comp < 4; ++comp) {
+                float x = acc[j][comp];
+                x += __shfl_xor(x, 16);
+                x += __shfl_xor(x, 32);
+                acc[j][comp] = x;
+            }
+        }
+        if ((tid & 63) < 16) {
+#pragma unroll
+            for (int j = 0; j < FIN_CPL; ++j) red[tid >> 6][l16 + 16 * j] = acc[j];
+        }
+        __syncthreads();
+        for (int ch = tid; ch < chunks; ch += 256) {
+            f32x4 b = bias ? ((const f32x4 *)bias)[ch] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            ((f32x4 *)(recon + m * d_out))[ch] = ((red[0][ch] + red[1][ch]) + (red[2][ch] + red[3][ch])) + b;
+        }
+    }
+}
+
 // one wavefront per token row: the row (minus b_dec) is held in registers, each selected encoder
 // column (a contiguous row of Pt, L2-resident) is dotted against it
 __global__ __launch_bounds__(256) void project_kernel(const float *x, long long M, int d_in, const float *b_dec,
@@ -280,6 +396,23 @@ int tsc_launch_decode_sparse(const float *W_dec, const float *bias, int d_out, c
     else
         hipLaunchKernelGGL(decode_sparse_kernel<1>, dim3((unsigned)M), dim3(256), 0, stream, W_dec, bias, d_out,
                            feat, val, count, max_active, recon);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
+int tsc_sparse_finish_supported(int d_out, int max_active) {
+    return d_out <= FIN_CPL * 16 * 4 && (d_out & 3) == 0 && max_active <= FIN_MAX_ACTIVE;
+}
+
+int tsc_launch_sparse_finish(const float *W_dec, const float *bias, int d_out, int *feat, float *val, const int *count,
+                             long long M, int max_active, const float *dirs, long long dir_stride, float *recon,
+                             float *scores, hipStream_t stream) {
+    if (M <= 0) return TSC_OK;
+    if (!tsc_sparse_finish_supported(d_out, max_active))
+        return tsc_fail(TSC_ERR_UNSUPPORTED, "fused lens pass needs d_out <= %d and max_active <= %d (got %d, %d)",
+                        FIN_CPL * 64, FIN_MAX_ACTIVE, d_out, max_active);
+    hipLaunchKernelGGL(sparse_finish_kernel, dim3((unsigned)M), dim3(256), 0, stream, W_dec, bias, d_out, feat, val,
+                       count, max_active, dirs, dir_stride, recon, scores);
     TSC_HIP_CHECK(hipGetLastError());
     return TSC_OK;
 }

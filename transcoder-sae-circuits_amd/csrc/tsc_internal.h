@@ -74,5 +74,9 @@ int tsc_launch_decode_sparse(const float *W_dec, const float *bias, int d_out, c
 int tsc_launch_contrib(const float *W_dec, int d_out, const int *feat, const float *val,
                        const int *count, long long M, int max_active, const float *dirs, int n_dir,
                        float *scores, hipStream_t stream);
+int tsc_sparse_finish_supported(int d_out, int max_active);
+int tsc_launch_sparse_finish(const float *W_dec, const float *bias, int d_out, int *feat, float *val, const int *count,
+                             long long M, int max_active, const float *dirs, long long dir_stride, float *recon,
+                             float *scores, hipStream_t stream);
 int tsc_launch_project(const float *x, long long M, int d_in, const float *b_dec, const float *Pt,
                        const float *bias, int F, int relu, float *out, hipStream_t stream);

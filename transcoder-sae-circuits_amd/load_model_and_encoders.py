@@ -75,8 +75,8 @@ def install_synthetic(device, n_layers: int = 12, d_sae: int = 24576, d_vocab: i
                       z_weights: Optional[Sequence] = None, t_weights: Optional[Sequence] = None, model=None):
     """Seed the cache with the stand-in GPT-2-shaped model and random-init dictionaries."""
     global model_encoder_cache, model_cache
-    from synthetic_dicts import make_dictionary_weights
-    from synthetic_model import SyntheticHookedTransformer
+    from standins.synthetic_dicts import make_dictionary_weights
+    from standins.synthetic_model import SyntheticHookedTransformer
 
     if model is None:
         model = SyntheticHookedTransformer(n_layers=n_layers, d_vocab=d_vocab, n_ctx=n_ctx, seed=seed, device=device)

@@ -21,6 +21,25 @@ BASIC_FILTER = None    # discovery_strategies.BASIC_FILTER / BASIC_STRATEGY live
 BASIC_STRATEGY = None  # which is not rebuilt; the arguments are accepted and stored for signature parity
 
 
+def top_k_token_ids(model, encoder, feature_type: str, layer: int, features, k: int = 5):
+    """``get_top_k_tokens`` for MANY features at once: the features' output directions
+    ``W_dec[F]`` (attention dictionaries: through ``W_O[layer]``, reference :157-163) as ONE ``[F, 768] x W_U``
+    product instead of one GEMV over the 154-MB unembedding per feature.  Returns ``(logits [F, k], ids [F, k])``."""
+    feats = torch.as_tensor(features, device=encoder.W_dec.device, dtype=torch.long).reshape(-1)
+    with torch.no_grad():
+        vecs = encoder.W_dec.detach().index_select(0, feats)                       # [F, d]
+        if feature_type == "attn":
+            w_o = model.W_O[layer]
+            vecs = vecs @ w_o.reshape(w_o.shape[0] * w_o.shape[1], w_o.shape[2])   # "f (n d), (n d) o -> f o"
+        top = (vecs @ model.W_U).topk(k, dim=1)
+    return top.values, top.indices
+
+
+def get_top_k_tokens_for_features(model, encoder, feature_type: str, layer: int, features, k: int = 5) -> List[List[str]]:
+    """The token strings of :func:`top_k_token_ids`, one list per feature."""
+    return [model.to_str_tokens(row) for row in top_k_token_ids(model, encoder, feature_type, layer, features, k)[1]]
+
+
 class MaxActAnalysis:
     num_sequences: int
 
@@ -93,14 +112,9 @@ class MaxActAnalysis:
         return self.active_examples[0].size(0)
 
     def get_top_k_tokens(self, k=5) -> List[str]:
-        """Tokens the feature's output direction promotes most (through ``W_U``)."""
-        if self.feature_type == "attn":
-            z_vec = self.encoder.W_dec[self.feature].reshape(self.model.cfg.n_heads, -1)
-            feature_vec = torch.einsum("nd,ndo->o", z_vec, self.model.W_O[self.layer])
-        else:
-            feature_vec = self.encoder.W_dec[self.feature]
-        logits = feature_vec @ self.model.W_U
-        return self.model.to_str_tokens(logits.topk(k).indices)
+        """Tokens the feature's output direction promotes most (through ``W_U``; reference :156-170)."""
+        ids = top_k_token_ids(self.model, self.encoder, self.feature_type, self.layer, [self.feature], k)[1][0]
+        return self.model.to_str_tokens(ids)
 
     def top_examples_all_features(self, k: int = 20):
         """New capability: the k max-activating tokens of EVERY feature of this dictionary in one fused

@@ -214,57 +214,68 @@ class SyntheticHookedTransformer(nn.Module):
         def put(name, value):
             if keep(name):
                 cache[name] = value
+            return value
 
+        out = self._forward(tokens, put, return_type, stop_at_layer)
+        return out, cache
+
+    @torch.no_grad()
+    def run_with_hooks(self, tokens: torch.Tensor, return_type: Optional[str] = "logits", fwd_hooks=(),
+                       stop_at_layer: Optional[int] = None, **_ignored):
+        """TransformerLens' ``run_with_hooks`` for forward hooks: ``fwd_hooks = [(name or name-filter, fn)]``,
+        ``fn(activation, hook=<object with .name>)``; a tensor returned by ``fn`` replaces the activation."""
+        table = []
+        for sel, fn in fwd_hooks:
+            table.append(((lambda n, s=sel: n == s) if isinstance(sel, str) else sel, fn))
+
+        def put(name, value):
+            for match, fn in table:
+                if match(name):
+                    res = fn(value, hook=SimpleNamespace(name=name))
+                    if res is not None:
+                        value = res
+            return value
+
+        return self._forward(tokens, put, return_type, stop_at_layer)
+
+    def _forward(self, tokens, put, return_type, stop_at_layer):
         cfg = self.cfg
         tokens = torch.as_tensor(tokens).to(self.device)
         if tokens.dim() == 1:
             tokens = tokens.unsqueeze(0)
         b, n = tokens.shape
-        embed = self.W_E[tokens]
-        pos_embed = self.W_pos[:n].unsqueeze(0).expand(b, -1, -1)
-        put("hook_embed", embed)
-        put("hook_pos_embed", pos_embed)
+        embed = put("hook_embed", self.W_E[tokens])
+        pos_embed = put("hook_pos_embed", self.W_pos[:n].unsqueeze(0).expand(b, -1, -1))
         resid = embed + pos_embed
         n_run = cfg.n_layers if stop_at_layer is None else min(stop_at_layer, cfg.n_layers)
         causal = torch.ones(n, n, dtype=torch.bool, device=self.device).tril()
         for l in range(n_run):
-            put(f"blocks.{l}.hook_resid_pre", resid)
+            resid = put(f"blocks.{l}.hook_resid_pre", resid)
             normed, scale = self._ln_pre(resid, cfg.eps)
             put(f"blocks.{l}.ln1.hook_scale", scale)
-            put(f"blocks.{l}.ln1.hook_normalized", normed)
-            q = torch.einsum("bpm,hmd->bphd", normed, self.W_Q[l]) + self.b_Q[l]
-            k = torch.einsum("bpm,hmd->bphd", normed, self.W_K[l]) + self.b_K[l]
-            v = torch.einsum("bpm,hmd->bphd", normed, self.W_V[l]) + self.b_V[l]
-            put(f"blocks.{l}.attn.hook_q", q)
-            put(f"blocks.{l}.attn.hook_k", k)
-            put(f"blocks.{l}.attn.hook_v", v)
+            normed = put(f"blocks.{l}.ln1.hook_normalized", normed)
+            q = put(f"blocks.{l}.attn.hook_q", torch.einsum("bpm,hmd->bphd", normed, self.W_Q[l]) + self.b_Q[l])
+            k = put(f"blocks.{l}.attn.hook_k", torch.einsum("bpm,hmd->bphd", normed, self.W_K[l]) + self.b_K[l])
+            v = put(f"blocks.{l}.attn.hook_v", torch.einsum("bpm,hmd->bphd", normed, self.W_V[l]) + self.b_V[l])
             scores = torch.einsum("bqhd,bkhd->bhqk", q, k) / math.sqrt(cfg.d_head)
-            scores = scores.masked_fill(~causal, float("-inf"))
-            put(f"blocks.{l}.attn.hook_attn_scores", scores)
-            pattern = scores.softmax(dim=-1)
-            put(f"blocks.{l}.attn.hook_pattern", pattern)
-            z = torch.einsum("bhqk,bkhd->bqhd", pattern, v)
-            put(f"blocks.{l}.attn.hook_z", z)
-            attn_out = torch.einsum("bqhd,hdm->bqm", z, self.W_O[l]) + self.b_O[l]
-            put(f"blocks.{l}.hook_attn_out", attn_out)
-            resid = resid + attn_out
-            put(f"blocks.{l}.hook_resid_mid", resid)
+            scores = put(f"blocks.{l}.attn.hook_attn_scores", scores.masked_fill(~causal, float("-inf")))
+            pattern = put(f"blocks.{l}.attn.hook_pattern", scores.softmax(dim=-1))
+            z = put(f"blocks.{l}.attn.hook_z", torch.einsum("bhqk,bkhd->bqhd", pattern, v))
+            attn_out = put(f"blocks.{l}.hook_attn_out", torch.einsum("bqhd,hdm->bqm", z, self.W_O[l]) + self.b_O[l])
+            resid = put(f"blocks.{l}.hook_resid_mid", resid + attn_out)
             normed2, scale2 = self._ln_pre(resid, cfg.eps)
             put(f"blocks.{l}.ln2.hook_scale", scale2)
-            put(f"blocks.{l}.ln2.hook_normalized", normed2)
-            mlp_out = self.blocks[l].mlp(normed2)
-            put(f"blocks.{l}.hook_mlp_out", mlp_out)
-            resid = resid + mlp_out
-            put(f"blocks.{l}.hook_resid_post", resid)
+            normed2 = put(f"blocks.{l}.ln2.hook_normalized", normed2)
+            mlp_out = put(f"blocks.{l}.hook_mlp_out", self.blocks[l].mlp(normed2))
+            resid = put(f"blocks.{l}.hook_resid_post", resid + mlp_out)
         if stop_at_layer is not None:
-            return resid, cache
+            return resid
         final, fscale = self._ln_pre(resid, cfg.eps)
         put("ln_final.hook_scale", fscale)
-        put("ln_final.hook_normalized", final)
-        logits = final @ self.W_U + self.b_U
+        final = put("ln_final.hook_normalized", final)
         if return_type is None:
-            return None, cache
-        return logits, cache
+            return None
+        return final @ self.W_U + self.b_U
 
     def forward(self, tokens, return_type="logits"):
         return self.run_with_cache(tokens, return_type=return_type, names_filter=lambda n: False)[0]

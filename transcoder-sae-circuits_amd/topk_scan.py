@@ -150,14 +150,66 @@ def hook_names(kind: str, layer: int, encoder=None) -> str:
     return getattr(getattr(encoder, "cfg", None), "hook_point", None) or f"blocks.{layer}.ln2.hook_normalized"
 
 
+class _HookedCapture:
+    """Upstream producer of the sweep: forward hooks write the wanted activations of a
+    batch straight into a preallocated ``[tokens, d_in]`` ring slot per dictionary -- no ``run_with_cache`` dict,
+    no per-batch allocation -- and the fused encode + top-k of that batch runs on a SIDE stream while the next
+    batch's model forward runs on the main one.  Two ring slots: slot ``b & 1`` is rewritten by batch ``b + 2``
+    only after the side stream has finished batch ``b`` (event ``done``)."""
+
+    def __init__(self, hooks: Dict[str, str], d_in: Dict[str, int], max_rows: int, device):
+        self.hooks = hooks
+        self.ring = {name: torch.empty(2, max_rows, d_in[name], dtype=torch.float32, device=device) for name in hooks}
+        self.side = torch.cuda.Stream(device=device)
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.done = [None, None]
+        self.batch = 0
+
+    def forward_and_feed(self, model, rows: torch.Tensor, stop_at: int, sweep: "MaxActSweep", base: int) -> None:
+        slot = self.batch & 1
+        main = torch.cuda.current_stream()
+        if self.done[slot] is not None:
+            main.wait_event(self.done[slot])  # the encodes that read this ring slot two batches ago
+        n_rows = rows.shape[0] * rows.shape[1]
+        by_hook: Dict[str, list] = {}
+        for name, hook in self.hooks.items():
+            by_hook.setdefault(hook, []).append(name)
+
+        def grab(act, hook):
+            flat = act.reshape(n_rows, -1)  # "b pos n d -> (b pos) (n d)", max_act_analysis.py:227
+            for name in by_hook[hook.name]:
+                self.ring[name][slot, :n_rows].copy_(flat)
+
+        with torch.no_grad():
+            model.run_with_hooks(rows, return_type=None, stop_at_layer=stop_at,
+                                 fwd_hooks=[(h, grab) for h in by_hook])
+        self.ready[slot].record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ready[slot])
+            sweep.feed({name: self.ring[name][slot, :n_rows] for name in self.hooks}, base)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.done[slot] = ev
+        self.batch += 1
+
+    def finish(self) -> None:
+        torch.cuda.current_stream().wait_stream(self.side)
+
+
 def sweep_model(model, tokens: torch.Tensor, z_saes: Optional[Sequence] = None, transcoders: Optional[Sequence] = None,
                 layers: Optional[Iterable[int]] = None, k: int = 20, batch_size: int = 128,
-                rank: int = 0, world: int = 1, engine_factory: Optional[Callable] = None, distributed: Optional[bool] = None):
+                rank: int = 0, world: int = 1, engine_factory: Optional[Callable] = None, distributed: Optional[bool] = None,
+                capture: str = "auto"):
     """Run ``model`` over ``tokens [n_seq, n_pos]`` and keep, for every feature of every given
     dictionary, the ``k`` max-activating tokens.  Token ids are ``seq * n_pos + pos`` (global), rank
     ``rank`` of ``world`` processes rows ``shard_rows(n_seq, rank, world)``.  Returns
     ``{"z_{L}" / "mlp_{L}": (vals, idx)}`` -- the keys of ``get_activation_dictionary``
-    (reference src/max_activating.py:55,63)."""
+    (reference src/max_activating.py:55,63).
+
+    ``capture``: ``"hooks"`` = forward hooks into a preallocated input ring, encodes on a side stream
+    (:class:`_HookedCapture`); ``"cache"`` = the reference's ``run_with_cache`` + dict per batch
+    (max_act_analysis.py:219-239); ``"auto"`` = hooks when the model offers ``run_with_hooks``, the engine is the
+    HIP one and the model lives on a GPU."""
     n_seq, n_pos = tokens.shape
     dicts, hooks = {}, {}
     n_layers = len(z_saes) if z_saes is not None else len(transcoders)
@@ -173,8 +225,21 @@ def sweep_model(model, tokens: torch.Tensor, z_saes: Optional[Sequence] = None, 
     start, stop = shard_rows(n_seq, rank, world)
     wanted = sorted(set(hooks.values()))
     stop_at = max(layers) + 1
+    dev = getattr(next(iter(dicts.values())), "W_enc", None)
+    on_gpu = dev is not None and dev.is_cuda
+    if capture == "auto":
+        capture = "hooks" if (hasattr(model, "run_with_hooks") and engine_factory is None and on_gpu) else "cache"
+    if capture not in ("hooks", "cache"):
+        raise ValueError(f"capture must be 'auto', 'hooks' or 'cache' (got {capture!r})")
+    producer = None
+    if capture == "hooks":
+        d_in = {name: int(d.W_enc.shape[0]) for name, d in dicts.items()}
+        producer = _HookedCapture(hooks, d_in, batch_size * n_pos, next(iter(dicts.values())).W_enc.device)
     for s in range(start, stop, batch_size):
         rows = tokens[s:min(s + batch_size, stop)]
+        if producer is not None:
+            producer.forward_and_feed(model, rows, stop_at, sweep, s * n_pos)
+            continue
         with torch.no_grad():
             _, cache = model.run_with_cache(rows, stop_at_layer=stop_at, names_filter=wanted)
         acts = {}
@@ -182,6 +247,8 @@ def sweep_model(model, tokens: torch.Tensor, z_saes: Optional[Sequence] = None, 
             a = cache[hook]
             acts[name] = a.reshape(a.shape[0] * a.shape[1], -1)  # "b pos n d -> (b pos) (n d)", max_act_analysis.py:227
         sweep.feed(acts, s * n_pos)
+    if producer is not None:
+        producer.finish()
     return sweep.result()
 
 

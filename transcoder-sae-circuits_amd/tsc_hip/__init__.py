@@ -19,6 +19,7 @@ _lib: Optional[ctypes.CDLL] = None
 F32, BF16 = 0, 1
 MAX_ACTIVE_LIMIT = 8192
 MAX_DIRS = 8
+LENS_PASS_MAX_ACTIVE = 2048  # tsc_sparse_lens_pass
 TOPK_MERGE_MAX = 2048              # include/tsc_hip.h: TSC_TOPK_MERGE_MAX
 STATIC_FLOOR_MAX_D_SAE = 131072    # include/tsc_hip.h: TSC_STATIC_FLOOR_MAX_D_SAE
 
@@ -48,6 +49,9 @@ _SIGNATURES = {
                                      _c.c_void_p, _c.c_void_p]),
     "tsc_contrib_scores": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int,
                                       _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "tsc_sparse_lens_pass": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                        _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p,
+                                        _c.c_void_p]),
     "tsc_project_features": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                         _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
 }
@@ -222,6 +226,46 @@ class DeviceDict:
             if cap >= min(MAX_ACTIVE_LIMIT, self.d_sae):
                 raise TscError(f"a row has {worst} active features, above the {MAX_ACTIVE_LIMIT} the sparse path holds")
             cap = min(MAX_ACTIVE_LIMIT, self.d_sae, max(2 * cap, worst))
+
+    def sparse_lens_pass(self, x: torch.Tensor, max_active: int = 512, dirs: Optional[torch.Tensor] = None,
+                         want_recon: bool = True, out: Optional[dict] = None):
+        """``tsc_sparse_lens_pass``: sparse emit + (sort, reconstruction, per-row direction scores) in two launches.
+
+        ``dirs``: ``[M, d_out]`` (one direction per row), ``[d_out]`` (shared) or None.  Returns ``(feat, val, count,
+        recon or None, scores [M, cap] or None)``.  No capacity check and no host sync: the caller compares
+        ``count.max()`` with ``feat.shape[1]`` once for as many dictionaries as it likes (``out`` may carry
+        preallocated ``feat/val/count`` views -- ``count`` then has to be zero already -- so that one memset and one
+        reduction serve a whole pass)."""
+        x2 = _dev(x, torch.float32, "x").reshape(-1, self.d_in)
+        m = x2.shape[0]
+        cap = max(1, min(int(max_active), LENS_PASS_MAX_ACTIVE, self.d_sae))
+        dev = x.device
+        if out is not None:
+            feat, val, count = out["feat"], out["val"], out["count"]
+            cap, zeroed = feat.shape[1], 1
+        else:
+            feat = torch.empty(m, cap, dtype=torch.int32, device=dev)
+            val = torch.empty(m, cap, dtype=torch.float32, device=dev)
+            count = torch.empty(m, dtype=torch.int32, device=dev)
+            zeroed = 0
+        recon = torch.empty(m, self.d_out, dtype=torch.float32, device=dev) if want_recon else None
+        scores, stride, dptr = None, 0, None
+        if dirs is not None:
+            dirs = _dev(dirs, torch.float32, "dirs")
+            if dirs.dim() == 2 and dirs.shape[0] == m and dirs.shape[1] == self.d_out:
+                stride = self.d_out if m > 1 or dirs.shape[0] == m else 0
+            elif dirs.numel() == self.d_out:
+                stride = 0
+            else:
+                raise TscError(f"dirs must be [{m}, {self.d_out}] or [{self.d_out}] (got {tuple(dirs.shape)})")
+            scores = torch.empty(m, cap, dtype=torch.float32, device=dev)
+            dptr = dirs.data_ptr()
+        with torch.cuda.device(dev):
+            _check(lib().tsc_sparse_lens_pass(self._handle, x2.data_ptr(), m, cap, feat.data_ptr(), val.data_ptr(),
+                                              count.data_ptr(), zeroed, dptr, stride,
+                                              recon.data_ptr() if recon is not None else None,
+                                              scores.data_ptr() if scores is not None else None, _stream()))
+        return feat, val, count, recon, scores
 
     def decode_rows(self, feat: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
         """``val[i] * W_dec[feat[i]]`` -> ``[n, d_out]``."""
