@@ -284,30 +284,34 @@ class _PromptCacheView:
 def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want_recon: bool = True):
     """All dictionaries of ``encoders`` (a list) over their ``inputs`` (a list of ``[R, d_in]`` tensors, the
     same R for all) with ONE host synchronisation: the counts of every dictionary live in one tensor that is
-    zeroed once, checked against the capacity once and copied to the host once.  ``dirs``: optional list of
-    per-dictionary direction tensors (``[R, d_out]`` or ``[d_out]``) for the fused contribution scores.
-    Returns ``(feat [D,R,cap], val [D,R,cap], count [D,R], recon list, scores list, counts on host [D,R])``."""
+    zeroed once, checked against the capacity once and copied to the host once, and the outputs of all
+    dictionaries are slices of stacked buffers (no per-dictionary allocation).  ``dirs``: optional ``[D, R, d_out]``
+    tensor (or list) of per-dictionary, per-row directions for the fused contribution scores.
+    Returns ``(feat [D,R,cap], val [D,R,cap], count [D,R], recon [D,R,d_out] or None, scores [D,R,cap] or None,
+    counts on host [D,R])``."""
     import tsc_hip
 
     n_d = len(encoders)
     rows = inputs[0].shape[0]
     dev = inputs[0].device
+    d_out = encoders[0].W_dec.shape[1]
     cap = max(1, min(int(max_active), tsc_hip.LENS_PASS_MAX_ACTIVE))
+    handles = [enc.device_dict() for enc in encoders]
     while True:
         feat = torch.empty(n_d, rows, cap, dtype=torch.int32, device=dev)
         val = torch.empty(n_d, rows, cap, dtype=torch.float32, device=dev)
         count = torch.zeros(n_d, rows, dtype=torch.int32, device=dev)
-        recons, scores = [], []
-        for i, (enc, x) in enumerate(zip(encoders, inputs)):
-            _, _, _, r, sc = enc.device_dict().sparse_lens_pass(
-                x, cap, dirs=None if dirs is None else dirs[i], want_recon=want_recon,
-                out={"feat": feat[i], "val": val[i], "count": count[i]})
-            recons.append(r)
-            scores.append(sc)
+        recon = torch.empty(n_d, rows, d_out, dtype=torch.float32, device=dev) if want_recon else None
+        scores = torch.empty(n_d, rows, cap, dtype=torch.float32, device=dev) if dirs is not None else None
+        for i, (h, x) in enumerate(zip(handles, inputs)):
+            h.sparse_lens_pass(x, cap, dirs=None if dirs is None else dirs[i],
+                               out={"feat": feat[i], "val": val[i], "count": count[i],
+                                    "recon": recon[i] if want_recon else None,
+                                    "scores": scores[i] if scores is not None else None})
         counts_host = count.cpu()  # the one synchronisation of the pass
         worst = int(counts_host.max()) if counts_host.numel() else 0
         if worst <= cap:
-            return feat, val, count, recons, scores, counts_host
+            return feat, val, count, recon, scores, counts_host
         if cap >= tsc_hip.LENS_PASS_MAX_ACTIVE:
             raise tsc_hip.TscError(f"a position has {worst} active features in one dictionary, above the "
                                    f"{tsc_hip.LENS_PASS_MAX_ACTIVE} the fused lens pass holds")
@@ -704,12 +708,32 @@ class BatchedCircuitLens:
         return w.reshape(w.shape[0] * w.shape[1], w.shape[2])
 
     def _encoders_and_inputs(self):
-        encs, xs = [], []
-        for layer in range(self.model.cfg.n_layers):
-            z = self._rows_of(("z", layer))
-            encs += [self.z_saes[layer], self.mlp_transcoders[layer]]
-            xs += [z.reshape(z.shape[0], -1).contiguous(), self._rows_of(("normalized", layer, "ln2")).contiguous()]
-        return encs, xs
+        """Encoders in dictionary order ``[z_0, mlp_0, z_1, mlp_1, ...]`` and their inputs at the covered rows
+        (gathered once: the pass, the error terms and every later ``direction_lens`` reuse them)."""
+        if getattr(self, "_inputs", None) is None:
+            encs, xs = [], []
+            for layer in range(self.model.cfg.n_layers):
+                z = self._rows_of(("z", layer))
+                encs += [self.z_saes[layer], self.mlp_transcoders[layer]]
+                xs += [z.reshape(z.shape[0], -1).contiguous(), self._rows_of(("normalized", layer, "ln2")).contiguous()]
+            self._inputs = (encs, xs)
+        return self._inputs
+
+    def _tables(self):
+        """Per-layer constants of the direction lens, stacked over layers once per batch."""
+        if getattr(self, "_tab", None) is None:
+            n_layers = self.model.cfg.n_layers
+            _, xs = self._encoders_and_inputs()
+            self._tab = {
+                "w_o_t": torch.stack([self._w_o_flat(l).t() for l in range(n_layers)]),            # [L, d_model, n*d]
+                "b_o": torch.stack([self.model.b_O[l] for l in range(n_layers)]),                   # [L, d_model]
+                "z_b_dec": torch.stack([self.z_saes[l].b_dec for l in range(n_layers)]),            # [L, n*d]
+                "t_b_out": torch.stack([self.mlp_transcoders[l].b_dec_out for l in range(n_layers)]),
+                "z": torch.stack(xs[0::2]),                                                         # [L, R, n*d]
+                "mlp_out": torch.stack([self._rows_of(("mlp_out", l)) for l in range(n_layers)]),   # [L, R, d_model]
+                "embed": self._rows_of("embed"), "pos_embed": self._rows_of("pos_embed"),
+            }
+        return self._tab
 
     def dictionary_pass(self, directions: Optional[torch.Tensor] = None):
         """Run (or return the cached) pass.  With ``directions`` (``[R, d_model]``, ``[n_prompts, d_model]`` with
@@ -721,15 +745,18 @@ class BatchedCircuitLens:
         encs, xs = self._encoders_and_inputs()
         dirs = None
         if directions is not None:
-            d = self._row_directions(directions)
-            dirs = []
-            for layer in range(self.model.cfg.n_layers):
-                dirs += [(d @ self._w_o_flat(layer).t()).contiguous(), d]
+            dirs = self._dictionary_directions(self._row_directions(directions))
         with torch.no_grad():
             out = run_dictionary_pass(encs, xs, self.max_active, dirs=dirs)
         if self._pass is None or directions is None:
             self._pass = out
         return out
+
+    def _dictionary_directions(self, d: torch.Tensor) -> torch.Tensor:
+        """``[D, R, d_out]``: row directions as each dictionary sees them (z-SAEs: pulled back through W_O)."""
+        n_layers = self.model.cfg.n_layers
+        dz = torch.matmul(d[None], self._tables()["w_o_t"])                       # [L, R, n*d]
+        return torch.stack([dz, d[None].expand(n_layers, -1, -1)], dim=1).reshape(2 * n_layers, *d.shape)
 
     def _row_directions(self, directions: torch.Tensor) -> torch.Tensor:
         d = directions.to(self.tokens.device, torch.float32)
@@ -743,11 +770,11 @@ class BatchedCircuitLens:
         return d.contiguous()
 
     def _pass_for_prompt(self, index: int):
-        feat, val, count, recons, _, counts_host = self.dictionary_pass()
+        feat, val, count, recon, _, counts_host = self.dictionary_pass()
         a = self._row_start[index]
         b = self._row_start[index + 1] if index + 1 < self.n_prompts else self.n_rows
         rowmap = None if self.positions == "all" else {self._row_pos_host[a]: 0}
-        return (feat[:, a:b], val[:, a:b], count[:, a:b], [r[a:b] for r in recons], counts_host[:, a:b].tolist(), rowmap)
+        return (feat[:, a:b], val[:, a:b], count[:, a:b], recon[:, a:b], counts_host[:, a:b].tolist(), rowmap)
 
     def lens(self, index: int) -> CircuitLens:
         if index not in self._views:
@@ -769,48 +796,64 @@ class BatchedCircuitLens:
         identity of each winner ``top_component [R, k]`` (index into ``component_names``), ``top_layer [R, k]``,
         ``top_feature [R, k]`` (-1 on auxiliary rows); ``-inf`` / -1 where a row has fewer than k components.
         Column layout per row = the ActiveFeatures row order with every feature block padded to the capacity."""
-        feat, val, count, recons, scores, _ = self.dictionary_pass(directions)
         d = self._row_directions(directions)
-        n_layers, cap, rows = self.model.cfg.n_layers, feat.shape[2], self.n_rows
-        dev = d.device
-        cols = [(self._rows_of("embed") * d).sum(-1, keepdim=True), (self._rows_of("pos_embed") * d).sum(-1, keepdim=True)]
-        slot = torch.arange(cap, device=dev)
-        masks = [torch.ones(rows, 2, dtype=torch.bool, device=dev)]
-        comp = [0, 1]
-        lay = [0, 0]
-        fcols = [torch.full((rows, 2), -1, dtype=torch.int64, device=dev)]
-        ones3 = torch.ones(rows, 3, dtype=torch.bool, device=dev)
-        minus = lambda n: torch.full((rows, n), -1, dtype=torch.int64, device=dev)  # noqa: E731
-        for layer in range(n_layers):
-            zi, mi = 2 * layer, 2 * layer + 1
-            dz = d @ self._w_o_flat(layer).t()
-            z = self._rows_of(("z", layer)).reshape(rows, -1)
-            cols += [(self.model.b_O[layer] * d).sum(-1, keepdim=True), ((z - recons[zi]) * dz).sum(-1, keepdim=True),
-                     (self.z_saes[layer].b_dec * dz).sum(-1, keepdim=True), scores[zi],
-                     ((self._rows_of(("mlp_out", layer)) - recons[mi]) * d).sum(-1, keepdim=True),
-                     (self.mlp_transcoders[layer].b_dec_out * d).sum(-1, keepdim=True), scores[mi]]
-            masks += [ones3, slot[None, :] < count[zi][:, None], ones3[:, :2], slot[None, :] < count[mi][:, None]]
-            comp += [2, 3, 4] + [5] * cap + [6, 7] + [8] * cap
-            lay += [layer] * (5 + 2 * cap)
-            fcols += [minus(3), feat[zi].long(), minus(2), feat[mi].long()]
-        raw = torch.cat(cols, dim=1)
-        mask = torch.cat(masks, dim=1)
-        raw = torch.where(mask, raw, torch.zeros_like(raw))
-        acts = raw / raw.sum(dim=1, keepdim=True)                     # normalize_activations (:551-554)
-        ranked = torch.where(mask, acts, torch.full_like(acts, float("-inf")))
-        kk = min(k, ranked.shape[1])
-        top_v, top_c = ranked.topk(kk, dim=1)
-        comp_t = torch.tensor(comp, device=dev)
-        lay_t = torch.tensor(lay, device=dev)
-        live = torch.isfinite(top_v)
-        return {
-            "activations": acts, "mask": mask, "raw": raw, "top_values": top_v,
-            "top_component": torch.where(live, comp_t[top_c], torch.full_like(top_c, -1)),
-            "top_layer": torch.where(live, lay_t[top_c], torch.full_like(top_c, -1)),
-            "top_feature": torch.where(live, torch.gather(torch.cat(fcols, dim=1), 1, top_c), torch.full_like(top_c, -1)),
-            "component_names": list(_COMPONENT_ORDER),
-            "row_prompt": self.row_prompt, "row_pos": self.row_pos,
-        }
+        encs, xs = self._encoders_and_inputs()
+        with torch.no_grad():
+            dirs = self._dictionary_directions(d)
+            feat, val, count, recon, scores, counts_host = run_dictionary_pass(encs, xs, self.max_active, dirs=dirs)
+            if self._pass is None:
+                self._pass = (feat, val, count, recon, scores, counts_host)
+            t = self._tables()
+            n_layers, cap, rows = self.model.cfg.n_layers, feat.shape[2], self.n_rows
+            dev = d.device
+            dz = dirs[0::2]                                                               # [L, R, n*d]
+            # auxiliary rows of every layer at once (row order of ActiveFeatures: b_O, z error, z bias | error, bias)
+            b_o = d @ t["b_o"].t()                                                        # [R, L]
+            z_err = ((t["z"] - recon[0::2]) * dz).sum(-1).t()
+            z_bias = (t["z_b_dec"][:, None, :] * dz).sum(-1).t()
+            t_err = ((t["mlp_out"] - recon[1::2]) * d[None]).sum(-1).t()
+            t_bias = d @ t["t_b_out"].t()
+            per_layer = torch.cat([torch.stack([b_o, z_err, z_bias], dim=2), scores[0::2].permute(1, 0, 2),
+                                   torch.stack([t_err, t_bias], dim=2), scores[1::2].permute(1, 0, 2)], dim=2)  # [R, L, 5+2cap]
+            head = torch.stack([(t["embed"] * d).sum(-1), (t["pos_embed"] * d).sum(-1)], dim=1)
+            raw = torch.cat([head, per_layer.reshape(rows, -1)], dim=1)
+            slot = torch.arange(cap, device=dev)
+            live_z = slot[None, None, :] < count[0::2].t()[:, :, None]                    # [R, L, cap]
+            live_m = slot[None, None, :] < count[1::2].t()[:, :, None]
+            ones = torch.ones(rows, n_layers, 3, dtype=torch.bool, device=dev)
+            mask = torch.cat([ones[:, 0, :2], torch.cat([ones, live_z, ones[:, :, :2], live_m], dim=2).reshape(rows, -1)], dim=1)
+            raw = torch.where(mask, raw, torch.zeros_like(raw))
+            acts = raw / raw.sum(dim=1, keepdim=True)                                     # normalize_activations (:551-554)
+            ranked = torch.where(mask, acts, torch.full_like(acts, float("-inf")))
+            kk = min(k, ranked.shape[1])
+            top_v, top_c = ranked.topk(kk, dim=1)
+            comp_t, lay_t = self._column_tables(cap, dev)
+            minus3 = torch.full((rows, n_layers, 3), -1, dtype=torch.int32, device=dev)
+            fcols = torch.cat([minus3[:, 0, :2], torch.cat([minus3, feat[0::2].permute(1, 0, 2), minus3[:, :, :2],
+                                                            feat[1::2].permute(1, 0, 2)], dim=2).reshape(rows, -1)], dim=1)
+            live = torch.isfinite(top_v)
+            neg = torch.full_like(top_c, -1)
+            return {
+                "activations": acts, "mask": mask, "raw": raw, "top_values": top_v,
+                "top_component": torch.where(live, comp_t[top_c], neg),
+                "top_layer": torch.where(live, lay_t[top_c], neg),
+                "top_feature": torch.where(live, torch.gather(fcols, 1, top_c).long(), neg),
+                "component_names": list(_COMPONENT_ORDER),
+                "row_prompt": self.row_prompt, "row_pos": self.row_pos,
+            }
+
+    def _column_tables(self, cap: int, dev):
+        """Component kind and layer of every column of the padded layout (static per capacity)."""
+        key = (cap, str(dev))
+        cache = self.__dict__.setdefault("_col_tables", {})
+        if key not in cache:
+            n_layers = self.model.cfg.n_layers
+            comp, lay = [0, 1], [0, 0]
+            for layer in range(n_layers):
+                comp += [2, 3, 4] + [5] * cap + [6, 7] + [8] * cap
+                lay += [layer] * (5 + 2 * cap)
+            cache[key] = (torch.tensor(comp, device=dev), torch.tensor(lay, device=dev))
+        return cache[key]
 
     def direction_lens_runs(self, directions: torch.Tensor, k: int = 10) -> List[List[ComponentLensWithValue]]:
         """``direction_lens`` as the per-prompt lists the reference's lens functions return (one list per covered

@@ -234,8 +234,8 @@ class DeviceDict:
         ``dirs``: ``[M, d_out]`` (one direction per row), ``[d_out]`` (shared) or None.  Returns ``(feat, val, count,
         recon or None, scores [M, cap] or None)``.  No capacity check and no host sync: the caller compares
         ``count.max()`` with ``feat.shape[1]`` once for as many dictionaries as it likes (``out`` may carry
-        preallocated ``feat/val/count`` views -- ``count`` then has to be zero already -- so that one memset and one
-        reduction serve a whole pass)."""
+        preallocated ``feat/val/count`` (and optionally ``recon/scores``) views -- ``count`` then has to be zero
+        already -- so that one memset and one reduction serve a whole pass)."""
         x2 = _dev(x, torch.float32, "x").reshape(-1, self.d_in)
         m = x2.shape[0]
         cap = max(1, min(int(max_active), LENS_PASS_MAX_ACTIVE, self.d_sae))
@@ -248,7 +248,9 @@ class DeviceDict:
             val = torch.empty(m, cap, dtype=torch.float32, device=dev)
             count = torch.empty(m, dtype=torch.int32, device=dev)
             zeroed = 0
-        recon = torch.empty(m, self.d_out, dtype=torch.float32, device=dev) if want_recon else None
+        recon = out.get("recon") if out is not None else None
+        if recon is None and want_recon:
+            recon = torch.empty(m, self.d_out, dtype=torch.float32, device=dev)
         scores, stride, dptr = None, 0, None
         if dirs is not None:
             dirs = _dev(dirs, torch.float32, "dirs")
@@ -258,7 +260,9 @@ class DeviceDict:
                 stride = 0
             else:
                 raise TscError(f"dirs must be [{m}, {self.d_out}] or [{self.d_out}] (got {tuple(dirs.shape)})")
-            scores = torch.empty(m, cap, dtype=torch.float32, device=dev)
+            scores = out.get("scores") if out is not None else None
+            if scores is None:
+                scores = torch.empty(m, cap, dtype=torch.float32, device=dev)
             dptr = dirs.data_ptr()
         with torch.cuda.device(dev):
             _check(lib().tsc_sparse_lens_pass(self._handle, x2.data_ptr(), m, cap, feat.data_ptr(), val.data_ptr(),
