@@ -31,6 +31,7 @@ extern "C" {
 
 #define TSC_F32 0  /* fp32 inputs/weights, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)            */
 #define TSC_BF16 1 /* bf16-rounded inputs/weights, fp32 accumulate (v_mfma_f32_32x32x16_bf16)  */
+#define TSC_F32_SCREEN 2 /* TSC_F32 for every entry point; tsc_sparse_lens_pass screens with the bf16 MFMA first */
 
 typedef struct tsc_dict tsc_dict_t; /* opaque: one transcoder or z-SAE resident on one GPU */
 typedef void *tsc_stream_t;         /* hipStream_t */
@@ -49,6 +50,9 @@ const char *tsc_last_error(void);
  * a 32768-row bf16 staging buffer for x (hipMalloc, freed by destroy); such a handle computes
  * relu(bf16(x - b_dec) @ bf16(W_enc) + b_enc) with fp32 accumulation, and its calls must not overlap
  * on different streams (they share the staging buffer).
+ * compute_dtype TSC_F32_SCREEN (needs d_in % 128 == 0) is TSC_F32 plus the operands of the bf16 SCREEN of
+ * tsc_sparse_lens_pass (the bf16 copy and staging buffer of TSC_BF16, and ||W_enc[:, n]||_2 per feature); results
+ * of every entry point are fp32 results, see tsc_sparse_lens_pass.
  * Every handle also owns bias' = b_enc - b_dec @ W_enc ([d_sae] fp32, summed in fp64): the encode
  * kernels contract the raw x and add bias', which equals the reference's
  * (x - b_dec) @ W_enc + b_enc (mlp_transcoder.py:200-212) up to fp32 rounding -- the same folding
@@ -215,10 +219,24 @@ int tsc_contrib_scores(const tsc_dict_t *dict, const int32_t *feat, const float 
  * Replaces, for all positions at once, the per-position z-SAE / transcoder forward, error terms, nonzero + topk,
  * W_dec gather (circuit_lens.py:585-653) and the lens dot product on the feature rows (:762-766).
  * Needs d_out <= 768 and max_active <= 2048 (else TSC_ERR_UNSUPPORTED: use the three separate calls).
+ *
+ * On a TSC_F32_SCREEN handle the emit is a two-stage EXACT computation: (1) the bf16 MFMA kernel (16x the fp32
+ * matrix rate) computes bf16(x - b_dec) @ bf16(W_enc) + b_enc + margin[n] and emits every feature for which that
+ * is positive -- margin[n] = bound * ||W_enc[:, n]||_2 + 2 d_in 2^-24 |b_enc[n]| is a proven bound of the difference
+ * between the exact fp32 pre-activation and the bf16 one (both bf16 roundings through Cauchy-Schwarz, plus the fp32
+ * accumulation error of both sums), so no feature with a positive exact activation is missed; (2) the second
+ * kernel recomputes each candidate exactly in fp32 (dot(x, W_enc^T[f]) + bias') and keeps the positive ones.
+ * Values are fp32 values (summed in a different order than tsc_encode_dense: they agree to ~1e-7 relative, and a
+ * feature whose pre-activation is within that of zero may be active in one and not the other).  count[m] above
+ * max_active then means "the CANDIDATES overflowed" (an upper bound of the active count): retry with that capacity.
+ * screen_row_bound: device pointer to ONE float >= (2^-8 * 1.01 + g) max_m ||x_m - b_dec|| + g (max_m ||x_m|| +
+ * ||b_dec||), g = 2 d_in 2^-24, or NULL = the library computes it (one more small kernel); ignored by other
+ * handles.  At most 32768 rows per call on such a handle.
  */
 int tsc_sparse_lens_pass(const tsc_dict_t *dict, const float *x, int64_t M, int max_active, int32_t *feat,
                          float *val, int32_t *count, int count_is_zero, const float *dirs,
-                         int64_t dir_row_stride, float *recon, float *scores, tsc_stream_t stream);
+                         int64_t dir_row_stride, float *recon, float *scores, const float *screen_row_bound,
+                         tsc_stream_t stream);
 
 /*
  * Scores of a few selected features for every token, without touching the other d_sae - F columns:

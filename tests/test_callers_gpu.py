@@ -286,6 +286,78 @@ def test_fused_lens_pass_matches_the_separate_kernels():
     assert torch.equal(small[2], count) and int(count.max()) > 8
 
 
+def _same_active_sets(feat_a, val_a, count_a, feat_b, val_b, count_b, atol=1e-6):
+    """Two sparse results agree: every feature whose activation exceeds ``2 atol`` on either side is on both sides
+    with the same value to fp32 rounding (``atol`` = the rounding noise of the fp32 sums, which grows with the
+    magnitude of the terms that cancel in them), each side sorted by value."""
+    worst, tiny = 0.0, 2 * atol
+    for m in range(feat_a.shape[0]):
+        a = {int(f): float(v) for f, v in zip(feat_a[m, :int(count_a[m])].tolist(), val_a[m, :int(count_a[m])].tolist())}
+        b = {int(f): float(v) for f, v in zip(feat_b[m, :int(count_b[m])].tolist(), val_b[m, :int(count_b[m])].tolist())}
+        for f in set(a) | set(b):
+            va, vb = a.get(f, 0.0), b.get(f, 0.0)
+            if max(va, vb) > tiny:
+                assert f in a and f in b, (m, f, va, vb)
+                assert abs(va - vb) <= 1e-5 * max(va, vb) + atol, (m, f, va, vb)
+                worst = max(worst, abs(va - vb))
+        vb_sorted = val_b[m, :int(count_b[m])]
+        assert bool((vb_sorted[:-1] >= vb_sorted[1:]).all())
+    return worst
+
+
+def test_screened_lens_pass_gives_the_exact_results():
+    """TSC_F32_SCREEN: bf16 MFMA screen + exact fp32 recompute of the candidates must find every active feature of
+    the plain fp32 pass with the same values -- on ordinary inputs, on inputs that sit close to a large b_dec (the
+    folded bias cancels to two digits: the worst case for the screen's error bound), on a ragged dictionary width,
+    and with the row bound computed by the library or handed in."""
+    import tsc_hip
+    from standins.synthetic_dicts import make_dictionary_weights
+
+    cases = []
+    w = gi.g1_full_weights()
+    x = torch.randn(300, 768, generator=torch.Generator().manual_seed(21))
+    cases.append((w, x, 256, 5e-6))  # two summation orders of a 768-term fp32 dot product whose terms are O(1)
+    wc = make_dictionary_weights(768, 1536, seed=31, b_enc=0.0)
+    gen = torch.Generator().manual_seed(32)
+    wc["b_dec"] = 3.0 * torch.randn(768, generator=gen)
+    wc["b_enc"] = torch.full_like(wc["b_enc"], -0.02)
+    # x @ W_enc and b_dec @ W_enc are ~50x the activations here and cancel: fp32 sums carry ~1e-6 of absolute noise
+    cases.append((wc, wc["b_dec"] + 0.05 * torch.randn(200, 768, generator=gen), 1024, 2e-5))
+    wr = make_dictionary_weights(768, 1000, seed=77, b_enc=-0.9)
+    xr = torch.randn(77, 768, generator=torch.Generator().manual_seed(5)) * torch.linspace(0.2, 3.0, 77)[:, None]  # row norms vary 15x
+    cases.append((wr, xr, 512, 1e-5))
+    for w, x, cap, atol in cases:
+        plain, _ = _dd(w)
+        screen, _ = _dd(w, compute_dtype=tsc_hip.F32_SCREEN)
+        xg = x.to(DEV)
+        dirs = torch.randn(x.shape[0], 768, generator=torch.Generator().manual_seed(1)).to(DEV)
+        fa, va, ca, ra, sa = plain.sparse_lens_pass(xg, cap, dirs=dirs)
+        fb, vb, cb, rb, sb = screen.sparse_lens_pass(xg, cap, dirs=dirs)                      # library computes the bound
+        bound = tsc_hip.screen_row_bound(xg, w["b_dec"].to(DEV)).reshape(1)
+        fc, vc, cc, rc, sc = screen.sparse_lens_pass(xg, cap, dirs=dirs, row_bound=bound)     # bound handed in
+        assert int(ca.max()) <= cap and int(cb.max()) <= cap
+        assert int(ca.sum()) > 20 * x.shape[0]  # the case is not vacuous
+        for f2, v2, c2, r2, s2 in ((fb, vb, cb, rb, sb), (fc, vc, cc, rc, sc)):
+            _same_active_sets(fa.cpu(), va.cpu(), ca.cpu(), f2.cpu(), v2.cpu(), c2.cpu(), atol)
+            _close(r2, ra, atol=1e-4)
+            # scores follow the (feature-matched) values
+            for m in (0, x.shape[0] - 1):
+                a = dict(zip(fa[m, :int(ca[m])].tolist(), sa[m, :int(ca[m])].tolist()))
+                b = dict(zip(f2[m, :int(c2[m])].tolist(), s2[m, :int(c2[m])].tolist()))
+                for f in a.keys() & b.keys():
+                    assert abs(a[f] - b[f]) <= 1e-5 * abs(a[f]) + 4 * atol
+        # the other entry points of a screening handle are the plain fp32 ones, bit for bit
+        assert torch.equal(screen.encode_dense(xg), plain.encode_dense(xg))
+        # the candidates may overflow a capacity that the true active set fits: reported through count, as documented
+        tight = int(ca.max())
+        ft, vt, ct, _, _ = screen.sparse_lens_pass(xg, tight, dirs=dirs)
+        over = ct > tight
+        ok_rows = (~over).nonzero().flatten().tolist()
+        if ok_rows:
+            _same_active_sets(fa[ok_rows].cpu(), va[ok_rows].cpu(), ca[ok_rows].cpu(), ft[ok_rows].cpu(), vt[ok_rows].cpu(),
+                              ct[ok_rows].cpu(), atol)
+
+
 def test_hooked_sweep_is_bit_identical_to_the_cache_sweep():
     """forward hooks into a preallocated input ring + encodes on a side stream give the same lists as
     the reference-shaped run_with_cache loop."""

@@ -27,6 +27,7 @@ class HipDictionaryMixin:
 
     _hip: Optional[tsc_hip.DeviceDict] = None
     _hip_bf16: Optional[tsc_hip.DeviceDict] = None
+    _hip_screen: Optional[tsc_hip.DeviceDict] = None
 
     def _out_bias(self) -> torch.Tensor:  # pragma: no cover - overridden
         raise NotImplementedError
@@ -40,17 +41,24 @@ class HipDictionaryMixin:
         if p.dtype != torch.float32:
             raise tsc_hip.TscError(f"{type(self).__name__} weights must be float32 (got {p.dtype})")
 
-    def device_dict(self, bf16: bool = False) -> tsc_hip.DeviceDict:
-        """The library handle for the current parameter storage (fp32, or the bf16-MFMA variant)."""
+    def device_dict(self, bf16: bool = False, screened: bool = False) -> tsc_hip.DeviceDict:
+        """The library handle for the current parameter storage: fp32, the bf16-MFMA variant, or (``screened``)
+        the fp32 handle that also carries the operands of the lens pass' bf16 screen -- fp32 results from every
+        entry point; dictionaries whose ``d_in`` is not a multiple of 128 get the plain fp32 handle."""
         self._require_gpu_fp32()
+        if screened and (bf16 or self.W_enc.shape[0] % 128 != 0 or self.W_dec.shape[1] > 768):
+            screened = False
         tensors = (self.W_enc.detach(), self.b_enc.detach(), self.b_dec.detach(), self.W_dec.detach(), self._out_bias().detach())
         tensors = tuple(t if t.is_contiguous() else t.contiguous() for t in tensors)
-        attr = "_hip_bf16" if bf16 else "_hip"
+        attr = "_hip_bf16" if bf16 else "_hip_screen" if screened else "_hip"
+        if attr == "_hip" and self._hip is None and self._hip_screen is not None:
+            attr = "_hip_screen"  # a screening handle does everything a plain fp32 handle does: do not keep two
         cur = getattr(self, attr)
         if cur is None or not cur.same_storage(*tensors):
             if cur is not None:
                 cur.close()
-            cur = tsc_hip.DeviceDict(*tensors, compute_dtype=tsc_hip.BF16 if bf16 else tsc_hip.F32)
+            cur = tsc_hip.DeviceDict(*tensors, compute_dtype=tsc_hip.BF16 if bf16 else
+                                     tsc_hip.F32_SCREEN if screened else tsc_hip.F32)
             object.__setattr__(self, attr, cur)
         else:
             cur.refresh_if_modified()

@@ -281,12 +281,16 @@ class _PromptCacheView:
         return t[self._i:self._i + 1, :self._n]
 
 
-def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want_recon: bool = True):
+def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want_recon: bool = True,
+                        screened: bool = True, row_bounds: Optional[torch.Tensor] = None):
     """All dictionaries of ``encoders`` (a list) over their ``inputs`` (a list of ``[R, d_in]`` tensors, the
     same R for all) with ONE host synchronisation: the counts of every dictionary live in one tensor that is
     zeroed once, checked against the capacity once and copied to the host once, and the outputs of all
     dictionaries are slices of stacked buffers (no per-dictionary allocation).  ``dirs``: optional ``[D, R, d_out]``
     tensor (or list) of per-dictionary, per-row directions for the fused contribution scores.
+    ``screened``: use the handles that screen the emit with the bf16 MFMA and recompute the candidates exactly in
+    fp32 (``TSC_F32_SCREEN``, include/tsc_hip.h) -- the same fp32 results, several times faster at CircuitLens sizes;
+    ``row_bounds [D]`` are the screens' row bounds (``tsc_hip.screen_row_bound``), computed here when not given.
     Returns ``(feat [D,R,cap], val [D,R,cap], count [D,R], recon [D,R,d_out] or None, scores [D,R,cap] or None,
     counts on host [D,R])``."""
     import tsc_hip
@@ -296,7 +300,10 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
     dev = inputs[0].device
     d_out = encoders[0].W_dec.shape[1]
     cap = max(1, min(int(max_active), tsc_hip.LENS_PASS_MAX_ACTIVE))
-    handles = [enc.device_dict() for enc in encoders]
+    screened = screened and rows <= 32768
+    handles = [enc.device_dict(screened=screened) for enc in encoders]
+    if screened and row_bounds is None:
+        row_bounds = torch.stack([tsc_hip.screen_row_bound(x, enc.b_dec.detach()) for enc, x in zip(encoders, inputs)])
     while True:
         feat = torch.empty(n_d, rows, cap, dtype=torch.int32, device=dev)
         val = torch.empty(n_d, rows, cap, dtype=torch.float32, device=dev)
@@ -305,6 +312,7 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
         scores = torch.empty(n_d, rows, cap, dtype=torch.float32, device=dev) if dirs is not None else None
         for i, (h, x) in enumerate(zip(handles, inputs)):
             h.sparse_lens_pass(x, cap, dirs=None if dirs is None else dirs[i],
+                               row_bound=row_bounds[i:i + 1] if screened and h.compute_dtype == tsc_hip.F32_SCREEN else None,
                                out={"feat": feat[i], "val": val[i], "count": count[i],
                                     "recon": recon[i] if want_recon else None,
                                     "scores": scores[i] if scores is not None else None})
@@ -719,6 +727,19 @@ class BatchedCircuitLens:
             self._inputs = (encs, xs)
         return self._inputs
 
+    def _row_bounds(self) -> Optional[torch.Tensor]:
+        """Row bounds of the bf16 screen for every dictionary ``[D]``: they depend on the inputs only, so one
+        batched computation serves every pass over this batch."""
+        if self.n_rows > 32768:
+            return None
+        if getattr(self, "_bounds", None) is None:
+            import tsc_hip
+
+            encs, xs = self._encoders_and_inputs()
+            with torch.no_grad():
+                self._bounds = tsc_hip.screen_row_bound(torch.stack(xs), torch.stack([e.b_dec.detach() for e in encs]))
+        return self._bounds
+
     def _tables(self):
         """Per-layer constants of the direction lens, stacked over layers once per batch."""
         if getattr(self, "_tab", None) is None:
@@ -747,7 +768,7 @@ class BatchedCircuitLens:
         if directions is not None:
             dirs = self._dictionary_directions(self._row_directions(directions))
         with torch.no_grad():
-            out = run_dictionary_pass(encs, xs, self.max_active, dirs=dirs)
+            out = run_dictionary_pass(encs, xs, self.max_active, dirs=dirs, row_bounds=self._row_bounds())
         if self._pass is None or directions is None:
             self._pass = out
         return out
@@ -800,7 +821,8 @@ class BatchedCircuitLens:
         encs, xs = self._encoders_and_inputs()
         with torch.no_grad():
             dirs = self._dictionary_directions(d)
-            feat, val, count, recon, scores, counts_host = run_dictionary_pass(encs, xs, self.max_active, dirs=dirs)
+            feat, val, count, recon, scores, counts_host = run_dictionary_pass(encs, xs, self.max_active, dirs=dirs,
+                                                                               row_bounds=self._row_bounds())
             if self._pass is None:
                 self._pass = (feat, val, count, recon, scores, counts_host)
             t = self._tables()

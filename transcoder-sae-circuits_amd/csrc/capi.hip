@@ -91,14 +91,14 @@ int tsc_dict_create(tsc_dict_t **out, int d_in, int d_sae, int d_out, int comput
     if (!W_enc || !b_enc || !b_dec) return tsc_fail(TSC_ERR_ARG, "W_enc, b_enc and b_dec are required");
     if (!aligned16(W_enc) || !aligned16(b_enc) || !aligned16(b_dec) || !aligned16(W_dec) || !aligned16(out_bias))
         return tsc_fail(TSC_ERR_ARG, "weight pointers must be 16-byte aligned");
-    if (compute_dtype != TSC_F32 && compute_dtype != TSC_BF16)
+    if (compute_dtype != TSC_F32 && compute_dtype != TSC_BF16 && compute_dtype != TSC_F32_SCREEN)
         return tsc_fail(TSC_ERR_ARG, "unknown compute dtype %d", compute_dtype);
     tsc_dict *d = new (std::nothrow) tsc_dict;
     if (!d) return tsc_fail(TSC_ERR_HIP, "out of host memory");
     memset(d, 0, sizeof(*d));
     d->d_in = d_in; d->d_sae = d_sae; d->d_out = d_out; d->compute_dtype = compute_dtype;
     d->W_enc = W_enc; d->b_enc = b_enc; d->b_dec = b_dec; d->W_dec = W_dec; d->out_bias = out_bias;
-    if (compute_dtype == TSC_BF16) {
+    if (compute_dtype == TSC_BF16 || compute_dtype == TSC_F32_SCREEN) {
         if (d_in & 127) {
             delete d;
             return tsc_fail(TSC_ERR_UNSUPPORTED, "bf16 path needs d_in %% 128 == 0 (got %d)", d_in);
@@ -112,8 +112,10 @@ int tsc_dict_create(tsc_dict_t **out, int d_in, int d_sae, int d_out, int comput
     }
     {
         hipError_t e = hipSuccess;
-        if (compute_dtype == TSC_F32 && d_in % 64 == 0)  // operand of the LDS-DMA kernel; other d_in use register staging
+        if (compute_dtype != TSC_BF16 && d_in % 64 == 0)  // operand of the LDS-DMA kernel; other d_in use register staging
             e = hipMalloc((void **)&d->W_enc_t, (size_t)d_in * d_sae * sizeof(float));
+        if (e == hipSuccess && compute_dtype == TSC_F32_SCREEN) e = hipMalloc((void **)&d->wnorm, (size_t)d_sae * sizeof(float));
+        if (e == hipSuccess && compute_dtype == TSC_F32_SCREEN) e = hipMalloc((void **)&d->screen_bound, 256);
         if (e == hipSuccess) e = hipMalloc((void **)&d->bias_fold, (size_t)d_sae * sizeof(float));
         int rc = e == hipSuccess ? tsc_dict_refresh(d, stream)
                                  : tsc_fail(TSC_ERR_HIP, "hipMalloc of the handle's derived operands failed: %s", hipGetErrorString(e));
@@ -145,6 +147,10 @@ int tsc_dict_refresh(tsc_dict_t *d, tsc_stream_t stream) {
         int rc = tsc_transpose_w_f32(d->W_enc, d->d_in, d->d_sae, d->W_enc_t, s);
         if (rc != TSC_OK) return rc;
     }
+    if (d->wnorm) {
+        int rc = tsc_launch_col_norms(d->W_enc, d->d_in, d->d_sae, d->wnorm, s);
+        if (rc != TSC_OK) return rc;
+    }
     return tsc_launch_fold_bias(d->W_enc, d->b_enc, d->b_dec, d->d_in, d->d_sae, d->bias_fold, s);
 }
 
@@ -154,6 +160,8 @@ int tsc_dict_destroy(tsc_dict_t *d) {
     if (d->x_bf16) (void)hipFree(d->x_bf16);
     if (d->W_enc_t) (void)hipFree(d->W_enc_t);
     if (d->bias_fold) (void)hipFree(d->bias_fold);
+    if (d->wnorm) (void)hipFree(d->wnorm);
+    if (d->screen_bound) (void)hipFree(d->screen_bound);
     delete d;
     return TSC_OK;
 }
@@ -291,7 +299,7 @@ static int check_decoder(const tsc_dict_t *d) {
 
 int tsc_sparse_lens_pass(const tsc_dict_t *d, const float *x, int64_t M, int max_active, int32_t *feat, float *val,
                          int32_t *count, int count_is_zero, const float *dirs, int64_t dir_row_stride, float *recon,
-                         float *scores, tsc_stream_t stream) {
+                         float *scores, const float *screen_row_bound, tsc_stream_t stream) {
     int rc = check_dict_x(d, x, M);
     if (rc) return rc;
     rc = check_decoder(d);
@@ -308,10 +316,25 @@ int tsc_sparse_lens_pass(const tsc_dict_t *d, const float *x, int64_t M, int max
     if (!count_is_zero) TSC_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)M * sizeof(int32_t), s));
     EncodeArgs a = base_args(d, x, M);
     a.sp_feat = feat; a.sp_val = val; a.sp_count = count; a.max_active = max_active;
+    if (d->compute_dtype == TSC_F32_SCREEN && d->W_enc_t) {
+        // bf16 MFMA screen (16x the fp32 matrix rate) -> candidates; the finish kernel recomputes them exactly in fp32
+        if (M > 32768) return tsc_fail(TSC_ERR_UNSUPPORTED, "screened lens pass takes at most 32768 rows per call (got %lld)", (long long)M);
+        if (!screen_row_bound) {
+            rc = tsc_launch_row_bound(x, M, d->d_in, d->b_dec, d->screen_bound, s);
+            if (rc) return rc;
+            screen_row_bound = d->screen_bound;
+        }
+        a.screen_wnorm = d->wnorm;
+        a.screen_bound = screen_row_bound;
+        rc = tsc_launch_encode_bf16(TSC_MODE_SPARSE, a, d->W_enc_bf16, d->x_bf16, s);
+        if (rc) return rc;
+        return tsc_launch_sparse_finish(d->W_dec, d->out_bias, d->d_out, feat, val, count, M, max_active, dirs,
+                                        dir_row_stride, recon, scores, x, d->W_enc_t, d->bias_fold, d->d_in, s);
+    }
     rc = run_encode(d, TSC_MODE_SPARSE, a, s);
     if (rc) return rc;
     return tsc_launch_sparse_finish(d->W_dec, d->out_bias, d->d_out, feat, val, count, M, max_active, dirs,
-                                    dir_row_stride, recon, scores, s);
+                                    dir_row_stride, recon, scores, nullptr, nullptr, nullptr, 0, s);
 }
 
 int tsc_decode_rows(const tsc_dict_t *d, const int32_t *feat, const float *val, int64_t n, float *rows,

@@ -164,6 +164,8 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
         const int n = n0 + wn0 + bn * 32 + li;
         nok[bn] = n < a.N;
         be[bn] = nok[bn] ? (DMA ? a.bias[n] : a.b_enc[n]) : 0.f;
+        if (BF16 && MODE == TSC_MODE_SPARSE && a.screen_wnorm && nok[bn])  // bf16 screen: see row_bound_kernel (encode_operands.hip)
+            be[bn] += *a.screen_bound * a.screen_wnorm[n] + 2.f * (float)a.K * 5.9604645e-8f * fabsf(be[bn]);
     }
 
     // TOPK: thread t < BN owns feature n0 + t of list set `slot`; its view of the list (kept in

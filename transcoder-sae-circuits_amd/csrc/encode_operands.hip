@@ -70,7 +70,65 @@ __global__ __launch_bounds__(256) void convert_x_kernel(const float *__restrict_
     *(uint4 *)(out + i * 8) = u.v;
 }
 
+// wnorm[n] = ||W[:, n]||_2, summed in fp64 and rounded UP (it scales an error bound)
+__global__ __launch_bounds__(256) void col_norm_kernel(const float *__restrict__ W, int K, int N, float *__restrict__ wnorm) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    double s = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const double w = (double)W[(size_t)k * N + n];
+        s += w * w;
+    }
+    wnorm[n] = __double2float_ru(sqrt(s) * (1.0 + 1e-6));
+}
+
+// Row bound of the bf16 screen, one wave per row, max over the rows by an atomic on the float's bits (the values
+// are non-negative, so unsigned order is float order):
+//   bound = (2^-8 * 1.01 + g) * ||x - b_dec||_2 + g * (||x||_2 + ||b_dec||_2),  g = 2 * K * 2^-24
+// first term: both bf16 roundings (2^-9 relative each) of every product, Cauchy-Schwarz over the row; second and
+// third: the fp32 accumulation error (K * 2^-24 relative to sum |x_k w_k|) of the exact kernel, which contracts the
+// raw x against the folded bias, and of the screen itself.  Multiplied by ||W_enc[:, n]||_2 it bounds
+// |exact pre-activation - screened pre-activation| of column n for every row, up to the g * |b_enc[n]| that the
+// screen kernel adds per column (the accumulation error on the bias both chains start from).
+__global__ __launch_bounds__(256) void row_bound_kernel(const float *__restrict__ x, long long M, int K,
+                                                       const float *__restrict__ b_dec, float *__restrict__ bound) {
+    const int lane = threadIdx.x & 63;
+    const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (row >= M) return;
+    float sc = 0.f, sr = 0.f, sb = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float v = x[row * K + k], b = b_dec[k];
+        sc += (v - b) * (v - b);
+        sr += v * v;
+        sb += b * b;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sc += __shfl_xor(sc, off);
+        sr += __shfl_xor(sr, off);
+        sb += __shfl_xor(sb, off);
+    }
+    if (lane == 0) {
+        const float g = 2.f * (float)K * 5.9604645e-8f;
+        const float r = ((0.00390625f * 1.01f + g) * sqrtf(sc) + g * (sqrtf(sr) + sqrtf(sb))) * 1.0001f;
+        atomicMax((unsigned *)bound, __float_as_uint(r));
+    }
+}
+
 }  // namespace
+
+int tsc_launch_col_norms(const float *W, int K, int N, float *wnorm, hipStream_t stream) {
+    hipLaunchKernelGGL(col_norm_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, W, K, N, wnorm);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
+int tsc_launch_row_bound(const float *x, long long M, int K, const float *b_dec, float *bound, hipStream_t stream) {
+    TSC_HIP_CHECK(hipMemsetAsync(bound, 0, sizeof(float), stream));
+    hipLaunchKernelGGL(row_bound_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, M, K, b_dec, bound);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
 
 size_t tsc_bf16_workspace_bytes(int K) { return (size_t)TSC_BF16_WS_ROWS * K * 2; }
 
@@ -90,6 +148,7 @@ int tsc_transpose_w_f32(const float *W, int K, int N, float *dst, hipStream_t st
 }
 
 int tsc_launch_encode_bf16(int mode, const EncodeArgs &a, const void *W_bf16, void *x_bf16, hipStream_t stream) {
+    // (a.screen_wnorm / a.screen_bound travel with the copy below: the bf16 SPARSE kernel then emits candidates)
     if (!W_bf16 || !x_bf16) return tsc_fail(TSC_ERR_ARG, "bf16 handle without its operand buffers");
     for (long long r0 = 0; r0 < a.M; r0 += TSC_BF16_WS_ROWS) {
         const long long rows = a.M - r0 < TSC_BF16_WS_ROWS ? a.M - r0 : TSC_BF16_WS_ROWS;

@@ -197,17 +197,26 @@ __global__ __launch_bounds__(256) void contrib_kernel(const float *W_dec, int d_
 // to tsc_contrib_scores).  grid = M, block = 256: 16 quarter waves, each takes the entries e = q, q + 16, ...
 constexpr int FIN_MAX_ACTIVE = 2048;  // sorted entries staged in LDS
 constexpr int FIN_CPL = 12;           // float4 chunks of a W_dec row per lane of a quarter wave: d_out <= 768
+// SCREENED: the emitted pairs are CANDIDATES from the bf16 screen (every feature whose exact activation is positive is
+// among them, plus the near misses).  Phase A recomputes each candidate's pre-activation exactly in fp32 --
+// dot(x[m], W_enc^T[f]) + bias'[f], a quarter wave per candidate over the contiguous row of the transposed copy --
+// and keeps the positive ones; count[m] becomes the true number of active features (unless the candidates
+// overflowed the capacity: then it is left above max_active so that the caller retries).
+template <bool SCREENED>
 __global__ __launch_bounds__(256) void sparse_finish_kernel(const float *W_dec, const float *bias, int d_out, int *feat,
-                                                           float *val, const int *count, int max_active,
+                                                           float *val, int *count, int max_active,
                                                            const float *dirs, long long dir_stride, float *recon,
-                                                           float *scores) {
+                                                           float *scores, const float *x, const float *W_enc_t,
+                                                           const float *bias_fold, int d_in) {
     __shared__ float sv[FIN_MAX_ACTIVE];
     __shared__ int sf[FIN_MAX_ACTIVE];
     __shared__ f32x4 sd[FIN_CPL * 16];        // the token's direction
     __shared__ f32x4 red[4][FIN_CPL * 16];    // per-wave partial reconstructions
+    __shared__ int n_live;
     const long long m = blockIdx.x;
     const int tid = threadIdx.x;
-    int c = count[m];
+    const int c_emitted = count[m];
+    int c = c_emitted;
     if (c > max_active) c = max_active;
     int *frow = feat + m * max_active;
     float *vrow = val + m * max_active;
@@ -218,7 +227,40 @@ __global__ __launch_bounds__(256) void sparse_finish_kernel(const float *W_dec, 
     }
     if (scores)
         for (int i = tid; i < chunks; i += 256) sd[i] = ((const f32x4 *)(dirs + m * dir_stride))[i];
+    if (SCREENED && tid == 0) n_live = 0;
     __syncthreads();
+    if constexpr (SCREENED) {
+        const int l16 = tid & 15, grp = tid >> 4;
+        const int kchunks = d_in >> 2;  // <= FIN_CPL * 16
+        f32x4 xr[FIN_CPL];
+#pragma unroll
+        for (int j = 0; j < FIN_CPL; ++j) {
+            const int ch = l16 + 16 * j;
+            xr[j] = ch < kchunks ? ((const f32x4 *)(x + m * d_in))[ch] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int e = grp; e < c; e += 16) {
+            const int f = sf[e];
+            const f32x4 *src = (const f32x4 *)(W_enc_t + (long long)f * d_in);
+            f32x4 w[FIN_CPL];
+#pragma unroll
+            for (int j = 0; j < FIN_CPL; ++j) {
+                const int ch = l16 + 16 * j;
+                w[j] = ch < kchunks ? src[ch] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < FIN_CPL; ++j)
+                part += w[j].x * xr[j].x + w[j].y * xr[j].y + w[j].z * xr[j].z + w[j].w * xr[j].w;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (l16 == 0) {
+                const float pre = part + bias_fold[f];
+                sv[e] = pre > 0.f ? pre : -1.f;  // -1 marks a near miss of the screen
+                if (pre > 0.f) atomicAdd(&n_live, 1);
+            }
+        }
+        __syncthreads();
+    }
     // rank sort (value descending, feature id ascending); a thread holds its entries' ranks across the barrier
     constexpr int EPT = FIN_MAX_ACTIVE / 256;
     float ev[EPT];
@@ -227,11 +269,11 @@ __global__ __launch_bounds__(256) void sparse_finish_kernel(const float *W_dec, 
     for (int j = 0; j < EPT; ++j) {
         const int e = tid + 256 * j;
         ev[j] = 0.f; ef[j] = 0; er[j] = -1;
-        if (e < c) {
+        if (e < c && (!SCREENED || sv[e] > 0.f)) {
             const float v = sv[e];
             const int f = sf[e];
             int rank = 0;
-            for (int i = 0; i < c; ++i) {
+            for (int i = 0; i < c; ++i) {  // near misses hold -1 and precede nothing
                 const float w = sv[i];
                 rank += (w > v || (w == v && sf[i] < f)) ? 1 : 0;
             }
@@ -239,6 +281,10 @@ __global__ __launch_bounds__(256) void sparse_finish_kernel(const float *W_dec, 
         }
     }
     __syncthreads();
+    if constexpr (SCREENED) {
+        c = n_live;
+        if (tid == 0 && c_emitted <= max_active) count[m] = c;
+    }
 #pragma unroll
     for (int j = 0; j < EPT; ++j)
         if (er[j] >= 0) {
@@ -404,15 +450,23 @@ int tsc_sparse_finish_supported(int d_out, int max_active) {
     return d_out <= FIN_CPL * 16 * 4 && (d_out & 3) == 0 && max_active <= FIN_MAX_ACTIVE;
 }
 
-int tsc_launch_sparse_finish(const float *W_dec, const float *bias, int d_out, int *feat, float *val, const int *count,
+int tsc_launch_sparse_finish(const float *W_dec, const float *bias, int d_out, int *feat, float *val, int *count,
                              long long M, int max_active, const float *dirs, long long dir_stride, float *recon,
-                             float *scores, hipStream_t stream) {
+                             float *scores, const float *x, const float *W_enc_t, const float *bias_fold, int d_in,
+                             hipStream_t stream) {
     if (M <= 0) return TSC_OK;
     if (!tsc_sparse_finish_supported(d_out, max_active))
         return tsc_fail(TSC_ERR_UNSUPPORTED, "fused lens pass needs d_out <= %d and max_active <= %d (got %d, %d)",
                         FIN_CPL * 64, FIN_MAX_ACTIVE, d_out, max_active);
-    hipLaunchKernelGGL(sparse_finish_kernel, dim3((unsigned)M), dim3(256), 0, stream, W_dec, bias, d_out, feat, val,
-                       count, max_active, dirs, dir_stride, recon, scores);
+    if (x) {
+        if (!W_enc_t || !bias_fold || d_in > FIN_CPL * 64 || (d_in & 3))
+            return tsc_fail(TSC_ERR_UNSUPPORTED, "screened lens pass needs the transposed W_enc copy and d_in <= %d", FIN_CPL * 64);
+        hipLaunchKernelGGL(sparse_finish_kernel<true>, dim3((unsigned)M), dim3(256), 0, stream, W_dec, bias, d_out, feat,
+                           val, count, max_active, dirs, dir_stride, recon, scores, x, W_enc_t, bias_fold, d_in);
+    } else {
+        hipLaunchKernelGGL(sparse_finish_kernel<false>, dim3((unsigned)M), dim3(256), 0, stream, W_dec, bias, d_out, feat,
+                           val, count, max_active, dirs, dir_stride, recon, scores, x, W_enc_t, bias_fold, d_in);
+    }
     TSC_HIP_CHECK(hipGetLastError());
     return TSC_OK;
 }

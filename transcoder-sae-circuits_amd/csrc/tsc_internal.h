@@ -13,6 +13,8 @@ struct tsc_dict {
     void *W_enc_bf16;                                       // owned (TSC_BF16 only): bf16(W_enc) transposed, [d_sae][d_in]
     void *x_bf16;                                           // owned (TSC_BF16 only): bf16(x - b_dec) of one chunk of rows
     float *bias_fold;                                       // owned: b_enc - b_dec @ W_enc (fp64 sums), [d_sae]
+    float *wnorm;                                           // owned (TSC_F32_SCREEN only): ||W_enc[:, n]||_2 rounded up, [d_sae]
+    float *screen_bound;                                    // owned (TSC_F32_SCREEN only): one float, the row bound of the current call
 };
 
 // error plumbing (capi.hip)
@@ -46,6 +48,10 @@ struct EncodeArgs {
     float *sp_val;
     int *sp_count;       // [M], zeroed by the caller
     int max_active;
+    // bf16 SCREEN of the sparse lens pass (capi.hip: tsc_sparse_lens_pass on a TSC_F32_SCREEN handle): the bias of column n
+    // is raised by *screen_bound * screen_wnorm[n], a proven bound of |exact fp32 - bf16| for that column, so every
+    // feature whose exact activation is positive is emitted as a candidate
+    const float *screen_wnorm, *screen_bound;
 };
 int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream);  // a.m_split <= 0: balanced
 int tsc_encode_recommended_slots(int d_sae, int bf16);
@@ -53,6 +59,8 @@ int tsc_encode_set_tuning(const char *key, int value);
 int tsc_launch_fold_bias(const float *W, const float *b_enc, const float *b_dec, int K, int N, float *out,
                          hipStream_t stream);
 int tsc_launch_encode_bf16(int mode, const EncodeArgs &a, const void *W_bf16, void *x_bf16, hipStream_t stream);
+int tsc_launch_col_norms(const float *W, int K, int N, float *wnorm, hipStream_t stream);
+int tsc_launch_row_bound(const float *x, long long M, int K, const float *b_dec, float *bound, hipStream_t stream);
 size_t tsc_bf16_workspace_bytes(int K);
 int tsc_pack_w_bf16(const float *W, int K, int N, void *dst, hipStream_t stream);
 int tsc_transpose_w_f32(const float *W, int K, int N, float *dst, hipStream_t stream);
@@ -75,8 +83,9 @@ int tsc_launch_contrib(const float *W_dec, int d_out, const int *feat, const flo
                        const int *count, long long M, int max_active, const float *dirs, int n_dir,
                        float *scores, hipStream_t stream);
 int tsc_sparse_finish_supported(int d_out, int max_active);
-int tsc_launch_sparse_finish(const float *W_dec, const float *bias, int d_out, int *feat, float *val, const int *count,
+int tsc_launch_sparse_finish(const float *W_dec, const float *bias, int d_out, int *feat, float *val, int *count,
                              long long M, int max_active, const float *dirs, long long dir_stride, float *recon,
-                             float *scores, hipStream_t stream);
+                             float *scores, const float *x, const float *W_enc_t, const float *bias_fold, int d_in,
+                             hipStream_t stream);
 int tsc_launch_project(const float *x, long long M, int d_in, const float *b_dec, const float *Pt,
                        const float *bias, int F, int relu, float *out, hipStream_t stream);

@@ -16,7 +16,7 @@ import torch
 _LIB_PATH = os.environ.get("TSC_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtsc_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
-F32, BF16 = 0, 1
+F32, BF16, F32_SCREEN = 0, 1, 2  # include/tsc_hip.h: TSC_F32, TSC_BF16, TSC_F32_SCREEN
 MAX_ACTIVE_LIMIT = 8192
 MAX_DIRS = 8
 LENS_PASS_MAX_ACTIVE = 2048  # tsc_sparse_lens_pass
@@ -51,7 +51,7 @@ _SIGNATURES = {
                                       _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "tsc_sparse_lens_pass": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p,
                                         _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p,
-                                        _c.c_void_p]),
+                                        _c.c_void_p, _c.c_void_p]),
     "tsc_project_features": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                         _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
 }
@@ -228,14 +228,15 @@ class DeviceDict:
             cap = min(MAX_ACTIVE_LIMIT, self.d_sae, max(2 * cap, worst))
 
     def sparse_lens_pass(self, x: torch.Tensor, max_active: int = 512, dirs: Optional[torch.Tensor] = None,
-                         want_recon: bool = True, out: Optional[dict] = None):
+                         want_recon: bool = True, out: Optional[dict] = None, row_bound: Optional[torch.Tensor] = None):
         """``tsc_sparse_lens_pass``: sparse emit + (sort, reconstruction, per-row direction scores) in two launches.
 
         ``dirs``: ``[M, d_out]`` (one direction per row), ``[d_out]`` (shared) or None.  Returns ``(feat, val, count,
         recon or None, scores [M, cap] or None)``.  No capacity check and no host sync: the caller compares
         ``count.max()`` with ``feat.shape[1]`` once for as many dictionaries as it likes (``out`` may carry
         preallocated ``feat/val/count`` (and optionally ``recon/scores``) views -- ``count`` then has to be zero
-        already -- so that one memset and one reduction serve a whole pass)."""
+        already -- so that one memset and one reduction serve a whole pass).  ``row_bound``: one-element device
+        tensor for a ``F32_SCREEN`` handle (see :func:`screen_row_bound`); None lets the library compute it."""
         x2 = _dev(x, torch.float32, "x").reshape(-1, self.d_in)
         m = x2.shape[0]
         cap = max(1, min(int(max_active), LENS_PASS_MAX_ACTIVE, self.d_sae))
@@ -268,7 +269,9 @@ class DeviceDict:
             _check(lib().tsc_sparse_lens_pass(self._handle, x2.data_ptr(), m, cap, feat.data_ptr(), val.data_ptr(),
                                               count.data_ptr(), zeroed, dptr, stride,
                                               recon.data_ptr() if recon is not None else None,
-                                              scores.data_ptr() if scores is not None else None, _stream()))
+                                              scores.data_ptr() if scores is not None else None,
+                                              _dev(row_bound, torch.float32, "row_bound").data_ptr() if row_bound is not None else None,
+                                              _stream()))
         return feat, val, count, recon, scores
 
     def decode_rows(self, feat: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
@@ -301,6 +304,16 @@ class DeviceDict:
             _check(lib().tsc_contrib_scores(self._handle, feat.data_ptr(), val.data_ptr(), count.data_ptr(), m, cap,
                                             dirs.data_ptr(), dirs.shape[0], out.data_ptr(), _stream()))
         return out
+
+
+def screen_row_bound(x: torch.Tensor, b_dec: torch.Tensor) -> torch.Tensor:
+    """The ``screen_row_bound`` of ``tsc_sparse_lens_pass`` (include/tsc_hip.h) for rows ``x [..., M, d_in]``: a
+    device tensor ``[...]`` of ``(2^-8 * 1.01 + g) max_m ||x_m - b_dec|| + g (max_m ||x_m|| + ||b_dec||)``,
+    ``g = 2 d_in 2^-24``, rounded up.  Leading axes batch over dictionaries (``b_dec [..., d_in]``)."""
+    g = 2.0 * x.shape[-1] * 2.0 ** -24
+    centred = (x - b_dec.unsqueeze(-2)).norm(dim=-1).amax(dim=-1)
+    raw = x.norm(dim=-1).amax(dim=-1)
+    return (((2.0 ** -8 * 1.01 + g) * centred + g * (raw + b_dec.norm(dim=-1))) * 1.0001).to(torch.float32).contiguous()
 
 
 class TopkState:
