@@ -215,7 +215,8 @@ int tsc_contrib_scores(const tsc_dict_t *dict, const int32_t *feat, const float 
  * i.e. tsc_contrib_scores with n_dir = 1 and a direction PER ROW (dir_row_stride >= d_out: every prompt has its
  * own logit-difference direction, task_evaluation.py:141-151) or one shared direction (dir_row_stride = 0).
  * scores has row pitch max_active; entries at i >= count[m] are 0.  Outputs feat/val/count as tsc_encode_sparse.
- * count_is_zero != 0: the caller has already zeroed count (one memset for the counts of many dictionaries).
+ * flags: TSC_LENS_COUNT_IS_ZERO = the caller has already zeroed count (one memset for the counts of many
+ * dictionaries); TSC_LENS_NO_SCREEN = plain fp32 emit even on a TSC_F32_SCREEN handle (see below).
  * Replaces, for all positions at once, the per-position z-SAE / transcoder forward, error terms, nonzero + topk,
  * W_dec gather (circuit_lens.py:585-653) and the lens dot product on the feature rows (:762-766).
  * Needs d_out <= 768 and max_active <= 2048 (else TSC_ERR_UNSUPPORTED: use the three separate calls).
@@ -233,8 +234,10 @@ int tsc_contrib_scores(const tsc_dict_t *dict, const int32_t *feat, const float 
  * ||b_dec||), g = 2 d_in 2^-24, or NULL = the library computes it (one more small kernel); ignored by other
  * handles.  At most 32768 rows per call on such a handle.
  */
+#define TSC_LENS_COUNT_IS_ZERO 1
+#define TSC_LENS_NO_SCREEN 2
 int tsc_sparse_lens_pass(const tsc_dict_t *dict, const float *x, int64_t M, int max_active, int32_t *feat,
-                         float *val, int32_t *count, int count_is_zero, const float *dirs,
+                         float *val, int32_t *count, int flags, const float *dirs,
                          int64_t dir_row_stride, float *recon, float *scores, const float *screen_row_bound,
                          tsc_stream_t stream);
 

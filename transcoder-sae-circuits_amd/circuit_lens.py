@@ -311,7 +311,7 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
         recon = torch.empty(n_d, rows, d_out, dtype=torch.float32, device=dev) if want_recon else None
         scores = torch.empty(n_d, rows, cap, dtype=torch.float32, device=dev) if dirs is not None else None
         for i, (h, x) in enumerate(zip(handles, inputs)):
-            h.sparse_lens_pass(x, cap, dirs=None if dirs is None else dirs[i],
+            h.sparse_lens_pass(x, cap, dirs=None if dirs is None else dirs[i], screen=screened,
                                row_bound=row_bounds[i:i + 1] if screened and h.compute_dtype == tsc_hip.F32_SCREEN else None,
                                out={"feat": feat[i], "val": val[i], "count": count[i],
                                     "recon": recon[i] if want_recon else None,
@@ -673,7 +673,7 @@ class BatchedCircuitLens:
       ``ActiveFeatures`` to the row's direction, normalised as ``normalize_activations`` does, and its top-k --
       ``feature_act x W_dec row . direction`` fused into the pass (no ``[comp, 768]`` matrix is built)."""
 
-    def __init__(self, prompts, positions: Union[str, int] = "all", max_active: int = 512):
+    def __init__(self, prompts, positions: Union[str, int] = "all", max_active: int = 512, screened: bool = True):
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         model, z_saes, mlp_transcoders = get_model_encoders(self.device)
         self.model, self.z_saes, self.mlp_transcoders = model, z_saes, mlp_transcoders
@@ -683,6 +683,7 @@ class BatchedCircuitLens:
         self.lengths = [int(model.to_tokens(p).shape[1]) for p in self.prompts]
         self.tokens = model.to_tokens(self.prompts)
         self.max_active = max_active
+        self.screened = screened  # bf16-screened emit (exact results, TSC_F32_SCREEN); False: the plain fp32 emit
         with torch.no_grad():
             self.logits, self.cache = model.run_with_cache(self.tokens, return_type="logits")
         self.positions = positions
@@ -730,7 +731,7 @@ class BatchedCircuitLens:
     def _row_bounds(self) -> Optional[torch.Tensor]:
         """Row bounds of the bf16 screen for every dictionary ``[D]``: they depend on the inputs only, so one
         batched computation serves every pass over this batch."""
-        if self.n_rows > 32768:
+        if self.n_rows > 32768 or not self.screened:
             return None
         if getattr(self, "_bounds", None) is None:
             import tsc_hip
@@ -768,7 +769,8 @@ class BatchedCircuitLens:
         if directions is not None:
             dirs = self._dictionary_directions(self._row_directions(directions))
         with torch.no_grad():
-            out = run_dictionary_pass(encs, xs, self.max_active, dirs=dirs, row_bounds=self._row_bounds())
+            out = run_dictionary_pass(encs, xs, self.max_active, dirs=dirs, screened=self.screened,
+                                      row_bounds=self._row_bounds())
         if self._pass is None or directions is None:
             self._pass = out
         return out
@@ -821,8 +823,8 @@ class BatchedCircuitLens:
         encs, xs = self._encoders_and_inputs()
         with torch.no_grad():
             dirs = self._dictionary_directions(d)
-            feat, val, count, recon, scores, counts_host = run_dictionary_pass(encs, xs, self.max_active, dirs=dirs,
-                                                                               row_bounds=self._row_bounds())
+            feat, val, count, recon, scores, counts_host = run_dictionary_pass(
+                encs, xs, self.max_active, dirs=dirs, screened=self.screened, row_bounds=self._row_bounds())
             if self._pass is None:
                 self._pass = (feat, val, count, recon, scores, counts_host)
             t = self._tables()

@@ -298,7 +298,7 @@ static int check_decoder(const tsc_dict_t *d) {
 }
 
 int tsc_sparse_lens_pass(const tsc_dict_t *d, const float *x, int64_t M, int max_active, int32_t *feat, float *val,
-                         int32_t *count, int count_is_zero, const float *dirs, int64_t dir_row_stride, float *recon,
+                         int32_t *count, int flags, const float *dirs, int64_t dir_row_stride, float *recon,
                          float *scores, const float *screen_row_bound, tsc_stream_t stream) {
     int rc = check_dict_x(d, x, M);
     if (rc) return rc;
@@ -313,10 +313,10 @@ int tsc_sparse_lens_pass(const tsc_dict_t *d, const float *x, int64_t M, int max
         return tsc_fail(TSC_ERR_UNSUPPORTED, "tsc_sparse_lens_pass needs d_out <= 768 and 1 <= max_active <= 2048 (got %d, %d); "
                         "use tsc_encode_sparse + tsc_decode_sparse + tsc_contrib_scores", d->d_out, max_active);
     hipStream_t s = (hipStream_t)stream;
-    if (!count_is_zero) TSC_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)M * sizeof(int32_t), s));
+    if (!(flags & TSC_LENS_COUNT_IS_ZERO)) TSC_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)M * sizeof(int32_t), s));
     EncodeArgs a = base_args(d, x, M);
     a.sp_feat = feat; a.sp_val = val; a.sp_count = count; a.max_active = max_active;
-    if (d->compute_dtype == TSC_F32_SCREEN && d->W_enc_t) {
+    if (d->compute_dtype == TSC_F32_SCREEN && d->W_enc_t && !(flags & TSC_LENS_NO_SCREEN)) {
         // bf16 MFMA screen (16x the fp32 matrix rate) -> candidates; the finish kernel recomputes them exactly in fp32
         if (M > 32768) return tsc_fail(TSC_ERR_UNSUPPORTED, "screened lens pass takes at most 32768 rows per call (got %lld)", (long long)M);
         if (!screen_row_bound) {

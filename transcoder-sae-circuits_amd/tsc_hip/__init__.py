@@ -228,7 +228,8 @@ class DeviceDict:
             cap = min(MAX_ACTIVE_LIMIT, self.d_sae, max(2 * cap, worst))
 
     def sparse_lens_pass(self, x: torch.Tensor, max_active: int = 512, dirs: Optional[torch.Tensor] = None,
-                         want_recon: bool = True, out: Optional[dict] = None, row_bound: Optional[torch.Tensor] = None):
+                         want_recon: bool = True, out: Optional[dict] = None, row_bound: Optional[torch.Tensor] = None,
+                         screen: bool = True):
         """``tsc_sparse_lens_pass``: sparse emit + (sort, reconstruction, per-row direction scores) in two launches.
 
         ``dirs``: ``[M, d_out]`` (one direction per row), ``[d_out]`` (shared) or None.  Returns ``(feat, val, count,
@@ -236,7 +237,8 @@ class DeviceDict:
         ``count.max()`` with ``feat.shape[1]`` once for as many dictionaries as it likes (``out`` may carry
         preallocated ``feat/val/count`` (and optionally ``recon/scores``) views -- ``count`` then has to be zero
         already -- so that one memset and one reduction serve a whole pass).  ``row_bound``: one-element device
-        tensor for a ``F32_SCREEN`` handle (see :func:`screen_row_bound`); None lets the library compute it."""
+        tensor for a ``F32_SCREEN`` handle (see :func:`screen_row_bound`); None lets the library compute it;
+        ``screen=False`` asks such a handle for the plain fp32 emit."""
         x2 = _dev(x, torch.float32, "x").reshape(-1, self.d_in)
         m = x2.shape[0]
         cap = max(1, min(int(max_active), LENS_PASS_MAX_ACTIVE, self.d_sae))
@@ -267,7 +269,7 @@ class DeviceDict:
             dptr = dirs.data_ptr()
         with torch.cuda.device(dev):
             _check(lib().tsc_sparse_lens_pass(self._handle, x2.data_ptr(), m, cap, feat.data_ptr(), val.data_ptr(),
-                                              count.data_ptr(), zeroed, dptr, stride,
+                                              count.data_ptr(), zeroed | (0 if screen else 2), dptr, stride,
                                               recon.data_ptr() if recon is not None else None,
                                               scores.data_ptr() if scores is not None else None,
                                               _dev(row_bound, torch.float32, "row_bound").data_ptr() if row_bound is not None else None,
