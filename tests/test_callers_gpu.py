@@ -440,3 +440,49 @@ def test_state_limits_and_infinite_activations():
     # padding ids decode to zero rows
     rows = d.decode_rows(torch.tensor([-1, 3], dtype=torch.int32, device=DEV), torch.tensor([2.0, 2.0], device=DEV))
     assert bool((rows[0] == 0).all()) and torch.allclose(rows[1], 2.0 * w["W_dec"][3].to(DEV))
+
+
+def test_sparse_emit_sorts_long_lists():
+    """A dense-ish dictionary: thousands of active features per position (the emit holds up to 8192), which takes
+    the bitonic path of the sort; the result must be the exact descending order of the library's own dense row."""
+    from standins.synthetic_dicts import make_dictionary_weights
+
+    w = make_dictionary_weights(768, 8192, seed=3, b_enc=0.05)
+    d, _ = _dd(w)
+    x = torch.randn(9, 768, generator=torch.Generator().manual_seed(4))
+    x[3] = x[2]  # equal rows: ties between positions are irrelevant, ties inside a row are broken by feature id
+    xg = x.to(DEV)
+    dense = d.encode_dense(xg)
+    feat, val, count = d.encode_sparse(xg, 8192)
+    assert torch.equal(count.long(), (dense > 0).sum(dim=1)) and int(count.min()) > 2000
+    for m in range(9):
+        c = int(count[m])
+        order = torch.sort(dense[m], descending=True, stable=True)
+        assert torch.equal(val[m, :c], order.values[:c]) and torch.equal(feat[m, :c].long(), order.indices[:c])
+        assert bool((feat[m, c:] == -1).all()) and bool((val[m, c:] == 0).all())
+    # a capacity between the rank-sort limit and the count: the overflow is reported, the kept prefix is sorted
+    f2, v2, c2 = d.encode_sparse(xg, 1024, check_capacity=False)
+    assert torch.equal(c2, count) and bool((v2[:, :-1] >= v2[:, 1:]).all())
+
+
+def test_module_copies_drop_handles_and_autograd_is_refused():
+    import copy
+    import pickle
+
+    import tsc_hip
+    from load_model_and_encoders import build_transcoder, build_zsae
+
+    g, wt, wz, x = gi.g1_inputs()
+    tc, zs = build_transcoder(wt, 8, DEV), build_zsae(wz, 8, DEV)
+    _close(tc.encode(x), g["tc_encode"])  # registers the handle
+    for clone in (copy.deepcopy(tc), pickle.loads(pickle.dumps(tc))):
+        assert clone._hip is None and clone.W_enc.data_ptr() != tc.W_enc.data_ptr()
+        _close(clone.encode(x), g["tc_encode"])
+    _close(copy.deepcopy(zs).encode(x), g["zs_encode"])
+    with torch.enable_grad():
+        xr = x.clone().to(DEV).requires_grad_()
+        with pytest.raises(tsc_hip.TscError):
+            tc.encode(xr)
+        with pytest.raises(tsc_hip.TscError):
+            zs(xr)
+        _close(tc.encode(x.to(DEV)), g["tc_encode"])  # inputs that do not require grad are fine with grad mode on

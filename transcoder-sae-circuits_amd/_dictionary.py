@@ -32,6 +32,34 @@ class HipDictionaryMixin:
     def _out_bias(self) -> torch.Tensor:  # pragma: no cover - overridden
         raise NotImplementedError
 
+    _HANDLE_ATTRS = ("_hip", "_hip_bf16", "_hip_screen", "_projectors")
+
+    def __getstate__(self):
+        """Library handles (ctypes pointers into this process' GPU context) never travel with a copy or a pickle:
+        ``copy.deepcopy`` / ``torch.save(module)`` get the parameters only and re-register on first use."""
+        state = dict(self.__dict__)
+        for name in self._HANDLE_ATTRS:
+            state.pop(name, None)
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+    def _refuse_autograd(self, x: torch.Tensor) -> None:
+        """The reference's encode is differentiable; the HIP kernels have no backward.  A caller that would
+        back-propagate through the dictionary gets an error instead of a silently missing gradient."""
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise tsc_hip.TscError(
+                "the MI355X encode has no backward: the input requires grad and autograd is enabled -- wrap the call "
+                "in torch.no_grad() (every analysis caller of the reference does, e.g. max_act_analysis.py:216) or use "
+                "the reference's PyTorch encode for attribution / training")
+
     def _require_gpu_fp32(self) -> None:
         p = self.W_enc
         if not p.is_cuda:

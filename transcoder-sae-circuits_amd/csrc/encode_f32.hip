@@ -278,6 +278,12 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
         default: __builtin_amdgcn_global_load_lds(G, L, 16, 3072, AUX); break;                         \
     }
     auto dma_piece = [&](int j, const char *xt, const char *wt, int buf, unsigned lds_a, unsigned lds_b) {
+#ifdef TSC_ABL_NODMA  // diagnosis builds only (wrong results): what the k-loop costs without its global -> LDS traffic
+        return;
+#endif
+#ifdef TSC_ABL_NODMA_B
+        if (j >= APW) return;
+#endif
         if (j < APW) {
             TSC_GLDS((gptr_t)(xt - 4096 + a_voff[j]),
                      (lptr_t)(size_t)(lds_a + buf * (unsigned)sizeof(sm.A[0]) + (j >> 2) * 4096), j & 3, TSC_X_AUX)
@@ -331,12 +337,19 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
         f32x4 af[WMB], bf[WNB];
     };
     auto ldfrag = [&](int buf, int kk, Frag &f) {
+#ifdef TSC_ABL_NOFRAG  // diagnosis builds only (wrong results): what the k-loop costs without its fragment reads
+        asm volatile("" : "+v"(f.af[0]), "+v"(f.bf[0]));
+        return;
+#endif
         const float *As = sm.A[buf];
         const float *Bs = sm.B[buf];
 #pragma unroll
         for (int bm = 0; bm < WMB; ++bm)
             f.af[bm] = *(const f32x4 *)&As[(wm0 + bm * 32 + li) * LDA_ +
                                            (DMA ? (((kk * 2 + lh) ^ ((li >> 1) & 7)) * 4) : kk * 8 + lh * 4)];
+#ifdef TSC_ABL_NOFRAG_B
+        return;
+#endif
 #pragma unroll
         for (int bn = 0; bn < WNB; ++bn) {
             if constexpr (DMA) {

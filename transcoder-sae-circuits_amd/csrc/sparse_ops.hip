@@ -16,32 +16,60 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int SORT_MAX = 8192;
 constexpr int DIR_MAX = 8;
 
-// grid = M, block = 256.  Rank sort in LDS: rank(e) = #entries that precede e.
+// grid = M, block = 256.  Short lists (the normal case, c ~ 64): rank sort in LDS, rank(e) = #entries that precede
+// e -- c^2 / 256 compares per thread and one pass.  Long lists (c > RANK_SORT_MAX, up to the 8192 the emit can hold):
+// bitonic sort of 64-bit keys (~value bits : feature id), ascending = value descending then feature ascending
+// (activations are positive floats, whose bit patterns order like the values) -- c log^2 c instead of c^2.
+constexpr int RANK_SORT_MAX = 512;
 __global__ __launch_bounds__(256) void sparse_sort_kernel(int *feat, float *val, const int *count,
                                                          int max_active) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float *sv = (float *)smem_raw;
-    int *sf = (int *)(smem_raw + sizeof(float) * max_active);
     const long long m = blockIdx.x;
     int c = count[m];
     if (c > max_active) c = max_active;
     int *frow = feat + m * max_active;
     float *vrow = val + m * max_active;
-    for (int e = threadIdx.x; e < c; e += blockDim.x) {
-        sv[e] = vrow[e];
-        sf[e] = frow[e];
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < c; e += blockDim.x) {
-        const float v = sv[e];
-        const int f = sf[e];
-        int rank = 0;
-        for (int j = 0; j < c; ++j) {
-            const float w = sv[j];
-            rank += (w > v || (w == v && sf[j] < f)) ? 1 : 0;
+    if (c <= RANK_SORT_MAX) {
+        float *sv = (float *)smem_raw;
+        int *sf = (int *)(smem_raw + sizeof(float) * RANK_SORT_MAX);
+        for (int e = threadIdx.x; e < c; e += blockDim.x) {
+            sv[e] = vrow[e];
+            sf[e] = frow[e];
         }
-        vrow[rank] = v;
-        frow[rank] = f;
+        __syncthreads();
+        for (int e = threadIdx.x; e < c; e += blockDim.x) {
+            const float v = sv[e];
+            const int f = sf[e];
+            int rank = 0;
+            for (int j = 0; j < c; ++j) {
+                const float w = sv[j];
+                rank += (w > v || (w == v && sf[j] < f)) ? 1 : 0;
+            }
+            vrow[rank] = v;
+            frow[rank] = f;
+        }
+    } else {
+        unsigned long long *key = (unsigned long long *)smem_raw;
+        int p2 = RANK_SORT_MAX * 2;
+        while (p2 < c) p2 <<= 1;
+        for (int e = threadIdx.x; e < p2; e += blockDim.x)
+            key[e] = e < c ? ((unsigned long long)(~__float_as_uint(vrow[e])) << 32) | (unsigned)frow[e] : ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= p2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = threadIdx.x; i < p2; i += blockDim.x) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const unsigned long long a = key[i], b = key[l];
+                        if ((a > b) == ((i & k) == 0)) { key[i] = b; key[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int e = threadIdx.x; e < c; e += blockDim.x) {
+            vrow[e] = __uint_as_float(~(unsigned)(key[e] >> 32));
+            frow[e] = (int)(unsigned)key[e];
+        }
     }
     // zero the unused tail so the buffers are fully defined
     for (int e = c + threadIdx.x; e < max_active; e += blockDim.x) {
@@ -413,7 +441,12 @@ int tsc_launch_sparse_sort(int *feat, float *val, const int *count, long long M,
     if (M <= 0) return TSC_OK;
     if (max_active > SORT_MAX)
         return tsc_fail(TSC_ERR_UNSUPPORTED, "max_active %d exceeds %d", max_active, SORT_MAX);
-    const size_t lds = (size_t)max_active * 8;
+    size_t lds = (size_t)RANK_SORT_MAX * 8;  // rank sort: two arrays of RANK_SORT_MAX; bitonic: next power of two of max_active keys
+    if (max_active > RANK_SORT_MAX) {
+        size_t p2 = (size_t)RANK_SORT_MAX * 2;
+        while (p2 < (size_t)max_active) p2 <<= 1;
+        lds = p2 * 8;
+    }
     hipLaunchKernelGGL(sparse_sort_kernel, dim3((unsigned)M), dim3(256), lds, stream, feat, val, count,
                        max_active);
     TSC_HIP_CHECK(hipGetLastError());

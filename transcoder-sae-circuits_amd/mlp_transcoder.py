@@ -71,6 +71,7 @@ class SparseTranscoder(HipDictionaryMixin, nn.Module):
     def encode(self, x):
         """``relu((x - b_dec) @ W_enc + b_enc)``; x is moved to the module's dtype/device first."""
         self._check_inner_hooks()
+        self._refuse_autograd(x)
         x = x.to(self.dtype).to(self.W_enc.device)
         acts = self.device_dict().encode_dense(x.contiguous())
         return self.hook_hidden_post(acts)

@@ -60,6 +60,7 @@ class ZSAE(HipDictionaryMixin, nn.Module):
         return out
 
     def encode(self, x):
+        self._refuse_autograd(x)
         x = x.to(self.W_enc.device)
         return self.device_dict().encode_dense(x.to(torch.float32).contiguous())
 
