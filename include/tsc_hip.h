@@ -154,6 +154,27 @@ int tsc_encode_topk_static(const tsc_dict_t *dict, const float *x, int64_t M, in
                            const tsc_topk_state_t *state, tsc_stream_t stream);
 
 /*
+ * tsc_encode_topk at the bf16 matrix rate with the lists of tsc_encode_topk, BIT FOR BIT (TSC_F32_SCREEN handles).
+ * Per chunk of 32768 rows: (1) the bf16 MFMA kernel computes bf16(x - b_dec) @ bf16(W_enc) + b_enc + margin[n]
+ * (margin: the proven bound of tsc_sparse_lens_pass) and queues every (token, feature) pair whose value reaches the
+ * feature's floor -- the k-th best over all slots before the call, state->floor, required -- one queue per
+ * workgroup in `workspace`; (2) a second kernel recomputes the queued pairs exactly in fp32, in the accumulation
+ * order of the fp32 MFMA kernel (a scalar fma chain reproduces v_mfma_f32_32x32x2_f32 bit for bit), and folds them
+ * into the lists; (3) the fp32 fused kernel is launched on the same chunk and returns at once unless a queue
+ * overflowed in (1) -- then (2) skipped the chunk and (3) does it exactly, so nothing is ever lost and no host
+ * round trip is needed.  Same ranking rule, same state layout, interchangeable with tsc_encode_topk call by call.
+ * Worth it once the lists are warm (few candidates per launch); on empty lists every positive activation is a
+ * candidate and step (3) usually takes over.  workspace: device memory of tsc_topk_screen_workspace_bytes(d_sae,
+ * n_slots) bytes, scratch between calls (calls sharing one workspace must be ordered on one stream).
+ * screen_row_bound as in tsc_sparse_lens_pass, over ALL rows of the call (NULL: computed per chunk).
+ * No reference counterpart beyond tsc_encode_topk's (max_act_analysis.py:215-249).
+ */
+size_t tsc_topk_screen_workspace_bytes(int d_sae, int n_slots);
+int tsc_encode_topk_screened(const tsc_dict_t *dict, const float *x, int64_t M, int64_t token_id_base,
+                             const tsc_topk_state_t *state, void *workspace, size_t workspace_bytes,
+                             const float *screen_row_bound, tsc_stream_t stream);
+
+/*
  * Merge n_lists list sets laid out [n_lists, d_sae, k] into out_vals/out_idx [d_sae, k], sorted
  * (value desc, token id asc), short lists padded with (0.0, -1).  n_lists * k <= 2048.
  * tsc_topk_finalize = merge of the state's slots.  tsc_topk_merge is also the step after the

@@ -1,0 +1,100 @@
+"""``tsc_encode_topk_screened``: the fused top-k with the contraction on the bf16 MFMA as a screen and an exact fp32
+recompute of the candidates must give the lists of ``tsc_encode_topk`` BIT FOR BIT -- values and token ids -- whatever
+the data: warm lists, cold lists (queue overflow -> the fp32 fallback launch), exact ties, ragged shapes, several
+slots, calls of both kinds interleaved on one state."""
+import pytest
+import torch
+
+import golden_inputs as gi
+from test_hip_kernels import _dd, _rank_own_dense
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _pair(w):
+    import tsc_hip
+
+    plain, _ = _dd(w)
+    screen, _ = _dd(w, compute_dtype=tsc_hip.F32_SCREEN)
+    return plain, screen
+
+
+@pytest.mark.parametrize("k,n_slots,batch", [(20, 4, 1024), (20, 1, 700), (7, 3, 333), (33, 2, 4096)])
+def test_screened_topk_is_bit_identical_small(k, n_slots, batch):
+    import tsc_hip
+
+    g, w, xs, n_seq, n_pos = gi.g2_inputs()  # d_sae 1536: 128-wide tiles, short queues
+    gen = torch.Generator().manual_seed(11)
+    a, b, c = xs[:900], xs[900:1500], xs[1500:2300]
+    x = torch.cat([a, b, a[:500], c, b, a[200:700], c[:50].repeat(6, 1)])  # repeated contexts: exact ties
+    x = x[torch.randperm(x.shape[0], generator=gen)].contiguous()
+    plain, screen = _pair(w)
+    xg = x.to(DEV)
+    exp_v, exp_i = _rank_own_dense(plain.encode_dense(xg), k, base=50)
+    ref = tsc_hip.TopkState(1536, k, DEV, n_slots=n_slots)
+    all_screened = tsc_hip.TopkState(1536, k, DEV, n_slots=n_slots)   # from the first call on: cold lists, overflow path
+    mixed = tsc_hip.TopkState(1536, k, DEV, n_slots=n_slots)          # fp32 first, then screened, then fp32 again
+    for j, s in enumerate(range(0, xg.shape[0], batch)):
+        chunk = xg[s:s + batch]
+        plain.encode_topk(chunk, 50 + s, ref)
+        screen.encode_topk_screened(chunk, 50 + s, all_screened)
+        if j == 0 or j % 3 == 2:
+            screen.encode_topk(chunk, 50 + s, mixed)
+        else:
+            screen.encode_topk_screened(chunk, 50 + s, mixed)
+    rv, ri = ref.finalize()
+    assert torch.equal(rv.cpu(), exp_v) and torch.equal(ri.cpu(), exp_i)
+    for st in (all_screened, mixed):
+        v, i = st.finalize()
+        assert torch.equal(v, rv), float((v - rv).abs().max())
+        assert torch.equal(i, ri), int((i != ri).sum())
+
+
+@pytest.mark.parametrize("d_sae", [24576, 49152])
+def test_screened_topk_is_bit_identical_full_width(d_sae):
+    """Real widths (256-wide tiles, 8 / 4 slots), 40 000 rows per call (two chunks of the staging buffer), lists warm
+    after the first call, exact ties across calls, a row bound handed in for the second half."""
+    import tsc_hip
+    from standins.synthetic_dicts import make_dictionary_weights
+
+    w = make_dictionary_weights(768, d_sae, seed=21, b_enc=-0.70 if d_sae == 24576 else -0.5)
+    plain, screen = _pair(w)
+    gen = torch.Generator(device=DEV).manual_seed(d_sae)
+    ref = tsc_hip.TopkState(d_sae, 20, DEV)
+    scr = tsc_hip.TopkState(d_sae, 20, DEV)
+    first = None
+    n_calls, rows = 5, 40000
+    for j in range(n_calls):
+        x = torch.randn(rows, 768, generator=gen, device=DEV)
+        if j == 0:
+            first = x[:3000].clone()
+        elif j % 2 == 0:
+            x[500:3500] = first  # the same contexts again
+        plain.encode_topk(x, j * rows, ref)
+        if j == 0:
+            screen.encode_topk(x, j * rows, scr)          # warm-up on the fp32 kernel, as a sweep would
+        elif j < 3:
+            screen.encode_topk_screened(x, j * rows, scr)
+        else:
+            bound = tsc_hip.screen_row_bound(x, w["b_dec"].to(DEV)).reshape(1)
+            screen.encode_topk_screened(x, j * rows, scr, row_bound=bound)
+    rv, ri = ref.finalize()
+    v, i = scr.finalize()
+    assert torch.equal(v, rv), float((v - rv).abs().max())
+    assert torch.equal(i, ri), int((i != ri).sum())
+    assert bool((ri[:, -1] >= 0).all())  # 200 000 tokens: every list is full
+
+
+def test_screened_topk_argument_checks():
+    import tsc_hip
+
+    g, w, xs, n_seq, n_pos = gi.g2_inputs()
+    plain, screen = _pair(w)
+    x = xs[:64].to(DEV)
+    st = tsc_hip.TopkState(1536, 20, DEV)
+    with pytest.raises(tsc_hip.TscError):
+        plain.encode_topk_screened(x, 0, st)             # not a screening handle
+    with pytest.raises(tsc_hip.TscError):
+        screen.encode_topk_screened(x, 0, tsc_hip.TopkState(1536, 20, DEV, cross_slot_floor=False))
+    assert tsc_hip.lib().tsc_topk_screen_workspace_bytes(24576, 8) > 8 * 96 * 8192 * 4

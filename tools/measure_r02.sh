@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r2m
 mkdir -p $O
 step() { echo "== $*"; timeout -k 10 "$@"; }
-step 240 rocprofv3 --kernel-trace --stats -d $O/bench_stats -o b --output-format csv -- python3 bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-config4 > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+step 240 rocprofv3 --kernel-trace --stats -d $O/bench_stats -o b --output-format csv -- python3 bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-config4 --no-screened > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 for shape in "24576 65536" "49152 65536" "131072 16384"; do
   set -- $shape
   for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do

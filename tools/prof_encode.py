@@ -17,6 +17,8 @@ ap.add_argument("--launches", type=int, default=12)
 ap.add_argument("--mode", default="topk", choices=["topk", "dense", "sparse"])
 ap.add_argument("--slots", type=int, default=0)
 ap.add_argument("--bf16", action="store_true")
+ap.add_argument("--screened", action="store_true", help="tsc_encode_topk_screened after --warm fp32 launches")
+ap.add_argument("--warm", type=int, default=2)
 ap.add_argument("--no-floor", action="store_true", help="without the cross-slot k-th-best floor")
 ap.add_argument("--b-enc", type=float, default=None, help="override b_enc (e.g. -100: nothing is ever active)")
 args = ap.parse_args()
@@ -28,7 +30,7 @@ dev = torch.device("cuda", 0)
 W, be, bd = make_device_dictionary(args.d_sae, 1, dev)
 if args.b_enc is not None:
     be.fill_(args.b_enc)
-d = tsc_hip.DeviceDict(W, be, bd, compute_dtype=tsc_hip.BF16 if args.bf16 else tsc_hip.F32)
+d = tsc_hip.DeviceDict(W, be, bd, compute_dtype=tsc_hip.BF16 if args.bf16 else tsc_hip.F32_SCREEN if args.screened else tsc_hip.F32)
 st = tsc_hip.TopkState(args.d_sae, 20, dev, n_slots=args.slots or None, cross_slot_floor=not args.no_floor)
 g = torch.Generator(device=dev).manual_seed(3)
 xs = [torch.randn(args.tokens, 768, generator=g, device=dev) for _ in range(args.launches)]
@@ -42,7 +44,9 @@ for i, x in enumerate(xs):
             torch.cuda.synchronize()
             _lib.tsc_debug_read_stamps((ctypes.c_ulonglong * 16)(), 1)
         e0.record()
-    if args.mode == "topk":
+    if args.mode == "topk" and args.screened and i >= args.warm:
+        d.encode_topk_screened(x, i * args.tokens, st)
+    elif args.mode == "topk":
         d.encode_topk(x, i * args.tokens, st)
     elif args.mode == "dense":
         out = d.encode_dense(x)

@@ -259,6 +259,33 @@ int tsc_encode_topk_static(const tsc_dict_t *d, const float *x, int64_t M, int64
     return tsc_encode_topk(d, x, M, token_id_base, &t, stream);
 }
 
+size_t tsc_topk_screen_workspace_bytes(int d_sae, int n_slots) {
+    if (d_sae <= 0 || n_slots < 1) return 0;
+    return tsc_screen_topk_workspace_bytes(d_sae, n_slots);
+}
+
+int tsc_encode_topk_screened(const tsc_dict_t *d, const float *x, int64_t M, int64_t token_id_base,
+                             const tsc_topk_state_t *s, void *workspace, size_t workspace_bytes,
+                             const float *screen_row_bound, tsc_stream_t stream) {
+    int rc = check_dict_x(d, x, M);
+    if (rc) return rc;
+    rc = check_state(s);
+    if (rc) return rc;
+    if (s->d_sae != d->d_sae)
+        return tsc_fail(TSC_ERR_ARG, "state d_sae %d does not match dictionary d_sae %d", s->d_sae, d->d_sae);
+    if (token_id_base < 0) return tsc_fail(TSC_ERR_ARG, "negative token id base");
+    if (d->compute_dtype != TSC_F32_SCREEN) return tsc_fail(TSC_ERR_ARG, "tsc_encode_topk_screened needs a TSC_F32_SCREEN handle");
+    if (!s->floor) return tsc_fail(TSC_ERR_ARG, "tsc_encode_topk_screened needs state->floor");
+    if (M == 0) return TSC_OK;
+    // the floor is what the screen compares against: the k-th best over ALL slots (also for a single slot)
+    if (!(s->flags & TSC_TOPK_FLOOR_KEEP)) {
+        rc = tsc_launch_topk_floor(s->vals, s->n_slots, s->d_sae, s->k, s->floor, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return tsc_launch_screen_topk(d, x, M, token_id_base, s->vals, (long long *)s->idx, s->n_slots, s->k, s->floor,
+                                  workspace, workspace_bytes, screen_row_bound, (hipStream_t)stream);
+}
+
 int tsc_topk_merge(const float *vals, const int64_t *idx, int n_lists, int d_sae, int k, float *out_vals,
                    int64_t *out_idx, tsc_stream_t stream) {
     if (!vals || !idx || !out_vals || !out_idx) return tsc_fail(TSC_ERR_ARG, "null list pointer");

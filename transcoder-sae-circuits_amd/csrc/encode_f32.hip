@@ -130,6 +130,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
     static_assert(!DMA || KALIGNED, "DMA staging has no k tail handling");
     static_assert(!LLDS || (DMA && MODE == TSC_MODE_TOPK), "LDS lists belong to the fused top-k DMA kernel");
     __shared__ Smem<C, DMA, LLDS> sm;
+    if (MODE == TSC_MODE_TOPK && a.run_flag && *a.run_flag == 0) return;  // fallback launch of the screen: nothing overflowed
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int wm0 = (wave / C::WVN) * (WMB * 32), wn0 = (wave % C::WVN) * (WNB * 32);
@@ -166,6 +167,17 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
         be[bn] = nok[bn] ? (DMA ? a.bias[n] : a.b_enc[n]) : 0.f;
         if (BF16 && MODE == TSC_MODE_SPARSE && a.screen_wnorm && nok[bn])  // bf16 screen: see row_bound_kernel (encode_operands.hip)
             be[bn] += *a.screen_bound * a.screen_wnorm[n] + 2.f * (float)a.K * 5.9604645e-8f * fabsf(be[bn]);
+    }
+    // SPARSE: a value is emitted when it exceeds this (0 = every positive activation; the top-k screen: just below the
+    // feature's floor, so that a value equal to the k-th best -- which a smaller token id may still outrank -- passes)
+    float sp_thr[WNB];
+#pragma unroll
+    for (int bn = 0; bn < WNB; ++bn) {
+        sp_thr[bn] = 0.f;
+        if (MODE == TSC_MODE_SPARSE && a.sq_floor && nok[bn]) {
+            const float fl = a.sq_floor[n0 + wn0 + bn * 32 + li];
+            sp_thr[bn] = fl > 0.f ? __uint_as_float(__float_as_uint(fl) - 1u) : 0.f;
+        }
     }
 
     // TOPK: thread t < BN owns feature n0 + t of list set `slot`; its view of the list (kept in
@@ -412,6 +424,12 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
             const int par = ep_tiles & 1;
             ++ep_tiles;
             auto direct = [&](long long row, int col, float v) {
+                if (a.sq_entries) {  // top-k screen: the workgroup's own candidate queue
+                    const int pos = atomicAdd(a.sq_counters + blockIdx.x, 1);
+                    if (pos < a.sq_cap) a.sq_entries[(size_t)blockIdx.x * a.sq_cap + pos] = ((unsigned)row << 8) | (unsigned)col;
+                    else *a.sq_overflow = 1;
+                    return;
+                }
                 const int pos = atomicAdd(a.sp_count + row, 1);
                 if (pos < a.max_active) {
                     a.sp_feat[row * a.max_active + pos] = n0 + col;
@@ -429,11 +447,25 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
                     direct(m0 + (loc >> 8), loc & 255, v);
                 }
             };
-            if (rows_left >= BM && n0 + BN <= a.N) {
-                TSC_FOR_ACC({ if (v > 0.f) emit(c, bn, v); })
-            } else {
-                TSC_FOR_ACC({ if (v > 0.f && nok[bn] && c < lim) emit(c, bn, v); })
-            }
+            // block by block: the lane's largest value of a 32x32 block first (15 v_max, no branch), the 16
+            // per-element tests only where it passes -- a fraction of a percent of the elements are emitted
+            const bool interior = rows_left >= BM && n0 + BN <= a.N;
+#pragma unroll
+            for (int bm = 0; bm < WMB; ++bm)
+#pragma unroll
+                for (int bn = 0; bn < WNB; ++bn) {
+                    float mx = acc[bm][bn][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[bm][bn][r]);
+                    if (mx > sp_thr[bn]) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int c = bm * 32 + (r & 3) + 8 * (r >> 2);
+                            const float v = acc[bm][bn][r];
+                            if (v > sp_thr[bn] && (interior || (nok[bn] && c < lim))) emit(c, bn, v);
+                        }
+                    }
+                }
             __syncthreads();
             const int staged = sm.sp_n[par] < SPQ ? sm.sp_n[par] : SPQ;
             if (tid == 0) sm.sp_n[par ^ 1] = 0;  // last read before this tile's barrier
@@ -849,7 +881,7 @@ bool pick_large(int mode, const EncodeArgs &a) {
     if (forced == 256) return true;
     if (a.N <= CfgSmall::BN) return false;  // a skinny dictionary (tsc_hip.FeatureProjector) would waste the wide tile
     const long long tiles = (long long)((a.N + CfgLarge::BN - 1) / CfgLarge::BN) * ((a.M + CfgLarge::BM - 1) / CfgLarge::BM);
-    if (mode == TSC_MODE_TOPK)  // the slots are fixed by the state: every one of them must get a wide tile
+    if (mode == TSC_MODE_TOPK || (mode == TSC_MODE_SPARSE && a.sq_entries))  // the slots are fixed by the state: every one of them must get a wide tile
         return (long long)((a.N + CfgLarge::BN - 1) / CfgLarge::BN) * a.m_split >= 256 &&
                (a.M + CfgLarge::BM - 1) / CfgLarge::BM >= a.m_split;
     return tiles >= 256;
@@ -935,6 +967,8 @@ int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream) {
     if (a.M <= 0) return TSC_OK;
     return pick_large(mode, a) ? dispatch<CfgLarge>(mode, a, stream) : dispatch<CfgSmall>(mode, a, stream);
 }
+
+int tsc_encode_tile_bn(int mode, const EncodeArgs &a) { return pick_large(mode, a) ? CfgLarge::BN : CfgSmall::BN; }
 
 // slot count that makes the fused top-k grid a whole number of waves of resident workgroups
 int tsc_encode_recommended_slots(int d_sae, int bf16) {

@@ -92,27 +92,40 @@ __global__ __launch_bounds__(256) void col_norm_kernel(const float *__restrict__
 // screen kernel adds per column (the accumulation error on the bias both chains start from).
 __global__ __launch_bounds__(256) void row_bound_kernel(const float *__restrict__ x, long long M, int K,
                                                        const float *__restrict__ b_dec, float *__restrict__ bound) {
-    const int lane = threadIdx.x & 63;
-    const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
-    if (row >= M) return;
-    float sc = 0.f, sr = 0.f, sb = 0.f;
-    for (int k = lane; k < K; k += 64) {
-        const float v = x[row * K + k], b = b_dec[k];
-        sc += (v - b) * (v - b);
-        sr += v * v;
-        sb += b * b;
+    __shared__ float wave_max[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long n_waves = (long long)gridDim.x * 4;
+    const float g = 2.f * (float)K * 5.9604645e-8f;
+    const int chunks = K >> 2;
+    float sb = 0.f;
+    for (int c = lane; c < chunks; c += 64) {
+        const float4 b = ((const float4 *)b_dec)[c];
+        sb += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        sc += __shfl_xor(sc, off);
-        sr += __shfl_xor(sr, off);
-        sb += __shfl_xor(sb, off);
+    for (int off = 32; off > 0; off >>= 1) sb += __shfl_xor(sb, off);
+    const float nb = sqrtf(sb);
+    float best = 0.f;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < M; row += n_waves) {
+        float sc = 0.f, sr = 0.f;
+        const float4 *xr = (const float4 *)(x + row * K);
+        for (int c = lane; c < chunks; c += 64) {
+            const float4 v = xr[c], b = ((const float4 *)b_dec)[c];
+            const float dx = v.x - b.x, dy = v.y - b.y, dz = v.z - b.z, dw = v.w - b.w;
+            sc += dx * dx + dy * dy + dz * dz + dw * dw;
+            sr += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sc += __shfl_xor(sc, off);
+            sr += __shfl_xor(sr, off);
+        }
+        best = fmaxf(best, ((0.00390625f * 1.01f + g) * sqrtf(sc) + g * (sqrtf(sr) + nb)) * 1.0001f);
     }
-    if (lane == 0) {
-        const float g = 2.f * (float)K * 5.9604645e-8f;
-        const float r = ((0.00390625f * 1.01f + g) * sqrtf(sc) + g * (sqrtf(sr) + sqrtf(sb))) * 1.0001f;
-        atomicMax((unsigned *)bound, __float_as_uint(r));
-    }
+    if (lane == 0) wave_max[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0)  // non-negative floats order like their bit patterns
+        atomicMax((unsigned *)bound, __float_as_uint(fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]))));
 }
 
 }  // namespace
@@ -125,7 +138,9 @@ int tsc_launch_col_norms(const float *W, int K, int N, float *wnorm, hipStream_t
 
 int tsc_launch_row_bound(const float *x, long long M, int K, const float *b_dec, float *bound, hipStream_t stream) {
     TSC_HIP_CHECK(hipMemsetAsync(bound, 0, sizeof(float), stream));
-    hipLaunchKernelGGL(row_bound_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, M, K, b_dec, bound);
+    long long blocks = (M + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(row_bound_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, M, K, b_dec, bound);
     TSC_HIP_CHECK(hipGetLastError());
     return TSC_OK;
 }

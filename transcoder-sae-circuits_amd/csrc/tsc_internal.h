@@ -52,9 +52,18 @@ struct EncodeArgs {
     // is raised by *screen_bound * screen_wnorm[n], a proven bound of |exact fp32 - bf16| for that column, so every
     // feature whose exact activation is positive is emitted as a candidate
     const float *screen_wnorm, *screen_bound;
+    // bf16 SCREEN of the fused top-k (screen_topk.hip): SPARSE epilogue, but a pair is emitted when its screened value
+    // reaches the feature's floor (k-th best over all slots), and it goes to the emitting workgroup's own queue
+    // sq_entries[w * sq_cap ..] as (row in this launch << 8 | column in tile); a full queue raises *sq_overflow
+    const float *sq_floor;
+    unsigned *sq_entries;
+    int *sq_counters, *sq_overflow;
+    int sq_cap;
+    const int *run_flag;  // when set: the whole launch returns at once unless *run_flag != 0 (the fp32 fallback of the screen)
 };
 int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream);  // a.m_split <= 0: balanced
 int tsc_encode_recommended_slots(int d_sae, int bf16);
+int tsc_encode_tile_bn(int mode, const EncodeArgs &a);  // column-tile width the launcher will pick for these arguments
 int tsc_encode_set_tuning(const char *key, int value);
 int tsc_launch_fold_bias(const float *W, const float *b_enc, const float *b_dec, int K, int N, float *out,
                          hipStream_t stream);
@@ -64,6 +73,12 @@ int tsc_launch_row_bound(const float *x, long long M, int K, const float *b_dec,
 size_t tsc_bf16_workspace_bytes(int K);
 int tsc_pack_w_bf16(const float *W, int K, int N, void *dst, hipStream_t stream);
 int tsc_transpose_w_f32(const float *W, int K, int N, float *dst, hipStream_t stream);
+
+// screen_topk.hip
+size_t tsc_screen_topk_workspace_bytes(int d_sae, int n_slots);
+int tsc_launch_screen_topk(const tsc_dict *d, const float *x, long long M, long long token_base, float *tk_vals,
+                           long long *tk_idx, int n_slots, int k, const float *floor, void *workspace,
+                           size_t workspace_bytes, const float *row_bound, hipStream_t stream);
 
 // topk_merge.hip
 int tsc_launch_topk_fill(float *vals, long long *idx, long long n, hipStream_t stream);

@@ -39,6 +39,9 @@ _SIGNATURES = {
     "tsc_topk_state_reset": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "tsc_encode_topk": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
     "tsc_encode_topk_static": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p]),
+    "tsc_topk_screen_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int]),
+    "tsc_encode_topk_screened": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p,
+                                            _c.c_size_t, _c.c_void_p, _c.c_void_p]),
     "tsc_topk_merge": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
                                   _c.c_void_p, _c.c_void_p]),
     "tsc_topk_finalize": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
@@ -193,6 +196,21 @@ class DeviceDict:
         with torch.cuda.device(x.device):
             _check(lib().tsc_encode_topk_static(self._handle, x2.data_ptr(), x2.shape[0], int(token_id_base),
                                                 ctypes.byref(state._struct), _stream()))
+
+    def encode_topk_screened(self, x: torch.Tensor, token_id_base: int, state: "TopkState",
+                             row_bound: Optional[torch.Tensor] = None) -> None:
+        """``tsc_encode_topk_screened`` (``F32_SCREEN`` handles): the lists of :meth:`encode_topk`, bit for bit, with
+        the contraction on the bf16 MFMA as a screen and an exact fp32 recompute of the few pairs that can enter a
+        list.  Interchangeable with :meth:`encode_topk` call by call; pays once the lists are warm."""
+        x2 = _dev(x, torch.float32, "x").reshape(-1, self.d_in)
+        ws = state.screen_workspace()
+        state._struct.flags = 0  # the screen compares against the floor: always fresh
+        state._calls += 1
+        with torch.cuda.device(x.device):
+            _check(lib().tsc_encode_topk_screened(
+                self._handle, x2.data_ptr(), x2.shape[0], int(token_id_base), ctypes.byref(state._struct), ws.data_ptr(),
+                ws.numel(), _dev(row_bound, torch.float32, "row_bound").data_ptr() if row_bound is not None else None,
+                _stream()))
 
     def encode_pre(self, x: torch.Tensor) -> torch.Tensor:
         """``(x - b_dec) @ W_enc + b_enc`` (no ReLU: the reference's ``hook_hidden_pre``)."""
@@ -357,6 +375,16 @@ class TopkState:
         keep = self._calls >= self.FLOOR_WARM_CALLS and self._calls % self.FLOOR_EVERY != 0
         self._struct.flags = 1 if keep else 0
         self._calls += 1
+
+    def screen_workspace(self) -> torch.Tensor:
+        """Candidate queues of ``tsc_encode_topk_screened`` (allocated on first use, scratch between calls)."""
+        if self.floor is None:
+            raise TscError("the screened top-k needs the state's floor scratch (cross_slot_floor=True)")
+        ws = getattr(self, "_screen_ws", None)
+        if ws is None:
+            n = int(lib().tsc_topk_screen_workspace_bytes(self.d_sae, self.n_slots))
+            ws = self._screen_ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+        return ws
 
     def finalize(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """Merged, sorted ``(vals [d_sae,k], idx [d_sae,k])``; the state stays usable."""
