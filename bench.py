@@ -621,15 +621,25 @@ def main(argv=None):
         if world > 1:
             out["lists_identical_on_all_ranks"] = identical
             out["collective_backend"] = "gloo (one-GPU rehearsal)" if host_collectives else "nccl (RCCL)"
+        # side objects never take the headline down with them: a failure is recorded in place of the object
         if world == 1 and not args.no_screened and engine.name == "hip" and not args.dict_widths:
-            out["screened_topk"] = screened_topk_side_object(engine, dicts, widths, xs, n_batches, B, K, W, args.k,
-                                                             rank_base, outs)
+            try:
+                out["screened_topk"] = screened_topk_side_object(engine, dicts, widths, xs, n_batches, B, K, W, args.k,
+                                                                 rank_base, outs)
+            except Exception as e:  # noqa: BLE001
+                out["screened_topk"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_config4 and engine.name == "hip":
             del xs, dicts, states
             torch.cuda.empty_cache()
-            out["config4"] = config4_side_object(device)
+            try:
+                out["config4"] = config4_side_object(device)
+            except Exception as e:  # noqa: BLE001
+                out["config4"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_tokens, args.cpu_tokens_one_thread)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_tokens, args.cpu_tokens_one_thread)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -16,7 +16,7 @@ import bench  # noqa: E402
 import load_model_and_encoders as lme  # noqa: E402
 from mlp_transcoder import SparseTranscoder  # noqa: E402
 from standins.synthetic_model import SyntheticHookedTransformer  # noqa: E402
-from topk_scan import sweep_model  # noqa: E402
+from topk_scan import HipTopkEngine, sweep_model  # noqa: E402
 from types import SimpleNamespace  # noqa: E402
 from z_sae import ZSAE  # noqa: E402
 
@@ -46,6 +46,15 @@ for mode in ("cache", "hooks", "cache", "hooks"):
     res[mode] = sweep_model(model, tokens, z_saes, tcs, k=20, batch_size=128, capture=mode, distributed=False)
     torch.cuda.synchronize()
     out[mode + "_tokens_per_s"] = n_seq * 128 / (time.perf_counter() - t0)  # the second round of each mode is kept
+# the same with the fp32 kernel only (round-1 behaviour); the engine factory disables the hook capture's "auto", so say it
+for mode in ("cache", "hooks", "cache", "hooks"):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = sweep_model(model, tokens, z_saes, tcs, k=20, batch_size=128, capture=mode, distributed=False,
+                    engine_factory=lambda d: HipTopkEngine(d, 20, screened=False))
+    torch.cuda.synchronize()
+    out[mode + "_fp32_only_tokens_per_s"] = n_seq * 128 / (time.perf_counter() - t0)
+out["fp32_only_lists_identical_to_screened"] = all(torch.equal(r[n][0], res["hooks"][n][0]) and torch.equal(r[n][1], res["hooks"][n][1]) for n in r)
 t0 = time.perf_counter()
 for s in range(0, n_seq, 128):
     model.run_with_hooks(tokens[s:s + 128], return_type=None, stop_at_layer=12, fwd_hooks=[])

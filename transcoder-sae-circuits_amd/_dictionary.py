@@ -96,9 +96,17 @@ class HipDictionaryMixin:
     def new_topk_state(self, k: int = 20, n_slots: Optional[int] = None) -> tsc_hip.TopkState:
         return tsc_hip.TopkState(self.W_enc.shape[1], k, self.W_enc.device, n_slots=n_slots)
 
-    def encode_topk(self, x: torch.Tensor, token_id_base: int, state: tsc_hip.TopkState, bf16: bool = False) -> None:
-        """Fused encode + per-feature running top-k; the activation matrix is never materialised."""
+    def encode_topk(self, x: torch.Tensor, token_id_base: int, state: tsc_hip.TopkState, bf16: bool = False,
+                    screened: bool = False) -> None:
+        """Fused encode + per-feature running top-k; the activation matrix is never materialised.  ``screened``: go
+        through ``tsc_encode_topk_screened`` (bf16 MFMA screen + exact fp32 recompute: the same lists bit for bit,
+        several times faster on warm lists) when the dictionary's shape allows it."""
         x = x.to(device=self.W_enc.device, dtype=torch.float32).contiguous()
+        if screened and not bf16 and state.floor is not None:
+            handle = self.device_dict(screened=True)
+            if handle.compute_dtype == tsc_hip.F32_SCREEN:
+                handle.encode_topk_screened(x, token_id_base, state)
+                return
         self.device_dict(bf16).encode_topk(x, token_id_base, state)
 
     def encode_sparse(self, x: torch.Tensor, max_active: int = 512):

@@ -23,14 +23,20 @@ import tsc_hip
 class HipTopkEngine:
     """Running top-k of one dictionary on the GPU."""
 
-    def __init__(self, dictionary, k: int = 20, bf16: bool = False):
+    SCREEN_AFTER_TOKENS = 32768  # the first batches run on the fp32 kernel: on cold lists every positive activation is a candidate
+
+    def __init__(self, dictionary, k: int = 20, bf16: bool = False, screened: bool = True):
         self.dictionary = dictionary
         self.k = k
         self.bf16 = bf16
+        self.screened = screened  # bit-identical lists either way (tsc_encode_topk_screened); False forces the fp32 kernel
         self.state = dictionary.new_topk_state(k)
+        self.tokens_seen = 0
 
     def update(self, x: torch.Tensor, token_id_base: int) -> None:
-        self.dictionary.encode_topk(x, token_id_base, self.state, bf16=self.bf16)
+        warm = self.screened and not self.bf16 and self.tokens_seen >= self.SCREEN_AFTER_TOKENS
+        self.dictionary.encode_topk(x, token_id_base, self.state, bf16=self.bf16, screened=warm)
+        self.tokens_seen += x.shape[0]
 
     def finalize(self) -> Tuple[torch.Tensor, torch.Tensor]:
         return self.state.finalize()
@@ -39,6 +45,7 @@ class HipTopkEngine:
         """Resume from finalized lists (they become the running state)."""
         dev = self.state.device
         self.state.load(vals.to(dev, torch.float32), idx.to(dev, torch.int64))
+        self.tokens_seen = self.SCREEN_AFTER_TOKENS  # resumed lists are warm
 
     @staticmethod
     def merge(vals: torch.Tensor, idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
