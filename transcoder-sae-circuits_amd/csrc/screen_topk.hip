@@ -24,6 +24,7 @@ namespace {
 
 constexpr int SQ_CAP_256 = 8192;   // queue entries per workgroup with 256-wide column tiles (half with 128-wide ones)
 constexpr int SQ_BATCH = 1024;
+constexpr int SQ_KL = 20;  // list length up to which an owner mirrors its list's values in LDS
 constexpr long long SQ_CHUNK_ROWS = 32768;  // = the bf16 staging buffer of the handle; row ids fit 15 bits
 
 __device__ __forceinline__ bool below(float v, long long id, float w, long long wid) {
@@ -44,6 +45,7 @@ template <int BN>
 __global__ __launch_bounds__(256) void screen_insert_kernel(const InsertArgs p) {
     __shared__ unsigned s_ent[SQ_BATCH];
     __shared__ float s_val[SQ_BATCH];
+    __shared__ float s_lv[BN * SQ_KL];  // k <= SQ_KL: the values of the owner's list (HBM is written through)
     if (*p.overflow) return;  // K3 redoes the whole chunk exactly
     const int w = blockIdx.x, tid = threadIdx.x;
     int n_cand = p.counters[w];
@@ -76,17 +78,19 @@ __global__ __launch_bounds__(256) void screen_insert_kernel(const InsertArgs p) 
             const float4 *xp = (const float4 *)(p.x + (size_t)(ent >> 8) * p.K);
             const float4 *wp = (const float4 *)(p.Wt + (size_t)n * p.K);
             float acc = p.bias[n];
-            // the accumulation order of the fp32 MFMA kernel, one rounding per product; the loads of 8 groups of 8 k
-            // (K % 64 == 0 on these handles) are issued together, the chain itself is sequential by definition
-            for (int g0 = 0; g0 < (p.K >> 3); g0 += 8) {
-                float4 xv[16], wv[16];
+            // the accumulation order of the fp32 MFMA kernel, one rounding per product.  A lane walks its own two rows:
+            // the 8 loads of one 128-byte line are issued back to back (first x's line, then W's), so that the line is
+            // still in the 32-KB L1 when its other pieces are asked for -- interleaving x and W loads and fetching two
+            // lines ahead was measured 8x amplified in L2 traffic.  (Staging the rows through LDS in 64-byte segments
+            // was tried: coalesced, but two barriers per 16 k make it latency-bound, 540 us against 230.)
+            for (int g0 = 0; g0 < (p.K >> 3); g0 += 4) {
+                float4 xv[8], wv[8];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    xv[j] = xp[2 * g0 + j];
-                    wv[j] = wp[2 * g0 + j];
-                }
+                for (int j = 0; j < 8; ++j) xv[j] = xp[2 * g0 + j];
 #pragma unroll
-                for (int j = 0; j < 16; j += 2) {
+                for (int j = 0; j < 8; ++j) wv[j] = wp[2 * g0 + j];
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
                     acc = fmaf(xv[j].x, wv[j].x, acc); acc = fmaf(xv[j + 1].x, wv[j + 1].x, acc);
                     acc = fmaf(xv[j].y, wv[j].y, acc); acc = fmaf(xv[j + 1].y, wv[j + 1].y, acc);
                     acc = fmaf(xv[j].z, wv[j].z, acc); acc = fmaf(xv[j + 1].z, wv[j + 1].z, acc);
@@ -103,6 +107,81 @@ __global__ __launch_bounds__(256) void screen_insert_kernel(const InsertArgs p) 
                 const float v = s_val[e];
                 if ((int)(ent & 255u) != tid || !(v > 0.f)) continue;
                 const long long id = p.token_base + (long long)(ent >> 8);
+                if (k <= SQ_KL) {
+                    // values mirrored in LDS: finding the new lowest entry after a replacement reads no HBM; ids are
+                    // fetched only to break exact ties (the same scheme as the fp32 kernel's owner, encode_f32.hip)
+                    float *mv = &s_lv[tid * SQ_KL];
+                    if (!loaded) {
+                        loaded = true;
+                        float ev[SQ_KL];
+#pragma unroll
+                        for (int i = 0; i < SQ_KL; ++i) ev[i] = lv[i < k ? i : k - 1];  // independent loads
+                        wid = -1;
+#pragma unroll
+                        for (int i = 0; i < SQ_KL; ++i)
+                            if (i < k) {
+                                mv[i] = ev[i];
+                                if (ev[i] > 0.f) {  // lists are compact and live values are positive
+                                    if (cnt == 0 || ev[i] <= wv) { wv = ev[i]; wpos = i; }  // among equal values: resolved below
+                                    cnt = i + 1;
+                                }
+                            }
+                        if (cnt > 0) {  // exact lowest-ranked entry: among equal lowest values the largest id
+                            int ties = 0;
+                            for (int i = 0; i < cnt; ++i) ties += mv[i] == wv;
+                            if (ties > 1) {
+                                long long best = -1;
+                                for (int i = 0; i < cnt; ++i)
+                                    if (mv[i] == wv) {
+                                        const long long t = lid[i];
+                                        if (t > best) { best = t; wpos = i; }
+                                    }
+                                wid = best;
+                            }
+                        }
+                    }
+                    if (cnt < k) {
+                        lv[cnt] = v;
+                        lid[cnt] = id;
+                        mv[cnt] = v;
+                        if (cnt == 0 || v < wv) { wv = v; wid = id; wpos = cnt; }
+                        else if (v == wv) {
+                            if (wid < 0) wid = lid[wpos];
+                            if (id > wid) { wid = id; wpos = cnt; }
+                        }
+                        ++cnt;
+                        continue;
+                    }
+                    if (v < wv) continue;
+                    if (v == wv) {
+                        if (wid < 0) wid = lid[wpos];
+                        if (id > wid) continue;
+                    }
+                    const int pos = wpos;
+                    lv[pos] = v;
+                    lid[pos] = id;
+                    mv[pos] = v;
+                    float lowest = v;
+                    int mp = pos, ties = 1;
+                    for (int i = 0; i < k; ++i) {
+                        if (i == pos) continue;
+                        const float e2 = mv[i];
+                        if (e2 < lowest) { lowest = e2; mp = i; ties = 1; }
+                        else if (e2 == lowest) ++ties;
+                    }
+                    wv = lowest; wpos = mp;
+                    wid = mp == pos ? id : -1;
+                    if (ties > 1) {
+                        long long best = -1;
+                        for (int i = 0; i < k; ++i)
+                            if (mv[i] == lowest) {
+                                const long long t = i == pos ? id : lid[i];
+                                if (t > best) { best = t; wpos = i; }
+                            }
+                        wid = best;
+                    }
+                    continue;
+                }
                 if (!loaded) {  // lists are compact: live entries first
                     loaded = true;
                     for (int i = 0; i < k; ++i) {
