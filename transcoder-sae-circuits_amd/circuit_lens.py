@@ -281,6 +281,16 @@ class _PromptCacheView:
         return t[self._i:self._i + 1, :self._n]
 
 
+_PASS_STREAMS: Dict[str, list] = {}
+
+
+def _pass_streams(dev, n: int = 4):
+    key = str(dev)
+    if key not in _PASS_STREAMS:
+        _PASS_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _PASS_STREAMS[key]
+
+
 def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want_recon: bool = True,
                         screened: bool = True, row_bounds: Optional[torch.Tensor] = None):
     """All dictionaries of ``encoders`` (a list) over their ``inputs`` (a list of ``[R, d_in]`` tensors, the
@@ -310,12 +320,26 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
         count = torch.zeros(n_d, rows, dtype=torch.int32, device=dev)
         recon = torch.empty(n_d, rows, d_out, dtype=torch.float32, device=dev) if want_recon else None
         scores = torch.empty(n_d, rows, cap, dtype=torch.float32, device=dev) if dirs is not None else None
+        # The dictionaries are independent and, at CircuitLens sizes, each one's two launches are too short to fill
+        # the chip (a 512-row emit is 8 us of bf16 MFMA work in a 43-us launch): spread them over a few HIP streams.
+        # Every buffer was allocated on the calling stream and outlives the pass; the side streams start after the
+        # calling stream's work so far and the calling stream waits for all of them before the counts are read.
+        main = torch.cuda.current_stream(dev)
+        side = _pass_streams(dev) if rows <= 8192 and n_d > 1 else []
+        start = torch.cuda.Event()
+        start.record(main)
         for i, (h, x) in enumerate(zip(handles, inputs)):
-            h.sparse_lens_pass(x, cap, dirs=None if dirs is None else dirs[i], screen=screened,
-                               row_bound=row_bounds[i:i + 1] if screened and h.compute_dtype == tsc_hip.F32_SCREEN else None,
-                               out={"feat": feat[i], "val": val[i], "count": count[i],
-                                    "recon": recon[i] if want_recon else None,
-                                    "scores": scores[i] if scores is not None else None})
+            stream = side[i % len(side)] if side else main
+            if side and i < len(side):
+                stream.wait_event(start)
+            with torch.cuda.stream(stream):
+                h.sparse_lens_pass(x, cap, dirs=None if dirs is None else dirs[i], screen=screened,
+                                   row_bound=row_bounds[i:i + 1] if screened and h.compute_dtype == tsc_hip.F32_SCREEN else None,
+                                   out={"feat": feat[i], "val": val[i], "count": count[i],
+                                        "recon": recon[i] if want_recon else None,
+                                        "scores": scores[i] if scores is not None else None})
+        for stream in side:
+            main.wait_stream(stream)
         counts_host = count.cpu()  # the one synchronisation of the pass
         worst = int(counts_host.max()) if counts_host.numel() else 0
         if worst <= cap:
