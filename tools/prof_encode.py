@@ -21,6 +21,8 @@ ap.add_argument("--screened", action="store_true", help="tsc_encode_topk_screene
 ap.add_argument("--warm", type=int, default=2)
 ap.add_argument("--no-floor", action="store_true", help="without the cross-slot k-th-best floor")
 ap.add_argument("--b-enc", type=float, default=None, help="override b_enc (e.g. -100: nothing is ever active)")
+ap.add_argument("--zero-operands", action="store_true",
+                help="x = 0 and W_enc = 0: the same instruction stream on operands that toggle no bits (power / clock check)")
 args = ap.parse_args()
 
 import tsc_hip  # noqa: E402
@@ -30,10 +32,16 @@ dev = torch.device("cuda", 0)
 W, be, bd = make_device_dictionary(args.d_sae, 1, dev)
 if args.b_enc is not None:
     be.fill_(args.b_enc)
+if args.zero_operands:
+    W.zero_()
+    bd.zero_()
 d = tsc_hip.DeviceDict(W, be, bd, compute_dtype=tsc_hip.BF16 if args.bf16 else tsc_hip.F32_SCREEN if args.screened else tsc_hip.F32)
 st = tsc_hip.TopkState(args.d_sae, 20, dev, n_slots=args.slots or None, cross_slot_floor=not args.no_floor)
 g = torch.Generator(device=dev).manual_seed(3)
 xs = [torch.randn(args.tokens, 768, generator=g, device=dev) for _ in range(args.launches)]
+if args.zero_operands:
+    for x in xs:
+        x.zero_()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 _lib = tsc_hip.lib()
