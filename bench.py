@@ -431,6 +431,9 @@ def parse_args(argv):
     ap.add_argument("--no-screened", action="store_true")
     # rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0, collectives over gloo
     ap.add_argument("--rehearse-on-one-gpu", action="store_true")
+    # with --gpus 1: still create the nccl (RCCL) process group (world size 1) and run every collective of the
+    # N > 1 path on the device -- the code-path check a one-GPU box allows for the RCCL branch
+    ap.add_argument("--exercise-collectives", action="store_true")
     # tests only: comma-separated dictionary widths instead of the config's 24, and a stand-in engine module
     ap.add_argument("--dict-widths", default=None)
     ap.add_argument("--engine-module", default=None)
@@ -463,10 +466,15 @@ def main(argv=None):
     device = engine.device
     host_collectives = args.rehearse_on_one_gpu or device.type != "cuda"
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.exercise_collectives
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if host_collectives:
             import datetime
 
@@ -507,7 +515,7 @@ def main(argv=None):
 
     def finish():
         outs = [engine.finalize(st) for st in states]
-        if world > 1:
+        if use_dist:
             from topk_scan import allgather_merge_many
 
             if host_collectives:  # gloo moves host tensors; the merge still runs on the device
@@ -517,7 +525,7 @@ def main(argv=None):
         return outs
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for s in range(W):
@@ -535,7 +543,7 @@ def main(argv=None):
     engine.sync()
     elapsed = time.perf_counter() - t0
     coll_dev = "cpu" if host_collectives else device
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -561,7 +569,7 @@ def main(argv=None):
             verified = verified and verify_slice(engine, dicts[i], xs[last % n_batches][i], rank_base + last * B,
                                                  v.to(device), ix.to(device))
     identical = None
-    if world > 1:
+    if use_dist:
         h = hashlib.sha256()
         for v, ix in outs:
             h.update(v.cpu().numpy().tobytes())
@@ -618,9 +626,11 @@ def main(argv=None):
                 "traffic_source": traffic_src,
             },
         }
-        if world > 1:
+        if use_dist:
             out["lists_identical_on_all_ranks"] = identical
             out["collective_backend"] = "gloo (one-GPU rehearsal)" if host_collectives else "nccl (RCCL)"
+            if world == 1:
+                out["collective_backend"] += ", world size 1 (code-path exercise on a one-GPU box)"
         # side objects never take the headline down with them: a failure is recorded in place of the object
         if world == 1 and not args.no_screened and engine.name == "hip" and not args.dict_widths:
             try:
@@ -641,7 +651,7 @@ def main(argv=None):
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if verified is False or identical is False:

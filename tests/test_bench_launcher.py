@@ -58,3 +58,14 @@ def test_world_size_must_match_gpus():
                         "cpu_bench_engine"], env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
     assert dict(os.environ) == env_backup
+
+
+def test_exercise_collectives_at_world_size_one():
+    """``--exercise-collectives`` runs every collective of the N > 1 path in a world of one (on the GPU box: the RCCL
+    branch; here gloo): the line stays an ``n_gpus: 1`` line and says which backend carried the exchange."""
+    p = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--tokens-per-step", "256", "--dict-widths", "96",
+              "--k", "5", "--engine-module", "cpu_bench_engine", "--no-cpu-baseline", "--exercise-collectives"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["verified"] is True and out["lists_identical_on_all_ranks"] is True
+    assert "world size 1" in out["collective_backend"]
