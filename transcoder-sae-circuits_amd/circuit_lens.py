@@ -24,6 +24,7 @@ Plotly heat maps are out of scope: ``visualize=True`` prints the ranked labels o
 from __future__ import annotations
 
 import bisect
+import os
 from dataclasses import dataclass
 from pprint import pprint
 from typing import Any, Dict, List, Optional, Tuple, TypedDict, Union
@@ -325,7 +326,8 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
         # Every buffer was allocated on the calling stream and outlives the pass; the side streams start after the
         # calling stream's work so far and the calling stream waits for all of them before the counts are read.
         main = torch.cuda.current_stream(dev)
-        side = _pass_streams(dev) if rows <= 8192 and n_d > 1 else []
+        n_side = int(os.environ.get("TSC_LENS_STREAMS", "4"))  # 1: everything on the current stream (profiling)
+        side = _pass_streams(dev, n_side) if rows <= 8192 and n_d > 1 and n_side > 1 else []
         start = torch.cuda.Event()
         start.record(main)
         for i, (h, x) in enumerate(zip(handles, inputs)):
