@@ -98,3 +98,33 @@ def test_screened_topk_argument_checks():
     with pytest.raises(tsc_hip.TscError):
         screen.encode_topk_screened(x, 0, tsc_hip.TopkState(1536, 20, DEV, cross_slot_floor=False))
     assert tsc_hip.lib().tsc_topk_screen_workspace_bytes(24576, 8) > 8 * 96 * 8192 * 4
+
+
+def test_screened_topk_with_non_finite_rows_matches_the_fp32_path():
+    """Rows holding NaN (their activations are NaN on both paths and enter no list; the row bound skips them) and a
+    row holding +inf (the bound becomes infinite, every pair is a candidate, the queues overflow and the fp32 launch
+    does the chunk) must leave the same lists as ``tsc_encode_topk``."""
+    import tsc_hip
+
+    g, w, xs, n_seq, n_pos = gi.g2_inputs()
+    plain, screen = _pair(w)
+    x = xs[:3000].clone()
+    x[17, 5] = float("nan")
+    x[1200] = float("nan")
+    xg = x.to(DEV)
+    ref = tsc_hip.TopkState(1536, 20, DEV, n_slots=2)
+    st = tsc_hip.TopkState(1536, 20, DEV, n_slots=2)
+    plain.encode_topk(xg[:1000], 0, ref)   # warm both states on the fp32 kernel
+    screen.encode_topk(xg[:1000], 0, st)
+    plain.encode_topk(xg[1000:], 1000, ref)
+    screen.encode_topk_screened(xg[1000:], 1000, st)   # NaN row 1200 inside a warm, screened call
+    y = xs[3000:4000].clone()
+    y[3, 100] = float("inf")
+    yg = y.to(DEV)
+    plain.encode_topk(yg, 3000, ref)
+    screen.encode_topk_screened(yg, 3000, st)
+    rv, ri = ref.finalize()
+    v, i = st.finalize()
+    assert torch.equal(i, ri), int((i != ri).sum())
+    assert torch.equal(torch.nan_to_num(v, nan=-7.0), torch.nan_to_num(rv, nan=-7.0))
+    assert not bool((ri == 1200).any()) and not bool((ri == 17).any())   # NaN rows are in no list
