@@ -263,6 +263,30 @@ int tsc_sparse_lens_pass(const tsc_dict_t *dict, const float *x, int64_t M, int 
                          tsc_stream_t stream);
 
 /*
+ * The tail of the CircuitLens pass for a batch of rows in ONE launch: per row, assemble the component scores in the
+ * ActiveFeatures row order, divide by the row's sum -- normalize_activations, circuit_lens.py:551-554 -- and select the
+ * k largest -- get_top_k_features, circuit_lens.py:161-164 (`activations.topk(k)`).
+ * A row has W = n_head + sum_g (group_aux[g] + max_active) columns: n_head leading scalars (embed, pos_embed), then for
+ * every group g its group_aux[g] auxiliary scalars (b_O, z error, z bias | error, bias) followed by the max_active
+ * score slots of dictionary g (tsc_sparse_lens_pass's `scores`), of which the first count[g][row] are live; dead
+ * slots read 0 in raw / acts, 0 in mask, and never rank.  group_aux: HOST array [n_groups], n_groups <= 64.
+ * head [R, n_head], aux [R, sum_g group_aux[g]] (group after group), scores [n_groups, R, max_active],
+ * count [n_groups, R]: device.  Optional device inputs: column_tags [n_head + sum_g group_aux[g] + n_groups] int32
+ * -- the caller's non-negative label of every column class: the head scalars, the auxiliary scalars group after
+ * group, then ONE per group for its score slots (CircuitLens packs component << 16 | layer) -- and feat
+ * [n_groups, R, max_active], the feature ids behind the score slots (tsc_sparse_lens_pass's `feat`).
+ * Outputs: raw / acts [R, W] fp32 and mask [R, W] bytes (each optional, NULL = skip; rows wider than 15360 columns
+ * need all three), top_values [R, k] and top_info [R, k, 4] int32 = (column in the row, tag >> 16, tag & 0xffff,
+ * feature id), all -1 (and -inf) where a row has fewer than k live columns, tag parts -1 without column_tags,
+ * feature -1 on non-slot columns or without feat.  Order: value descending, column ascending; NaN never ranks.
+ * k <= 256, n_head <= 256, group_aux[g] <= 256.
+ */
+int tsc_lens_assemble(int64_t R, int n_head, int n_groups, const int32_t *group_aux, int max_active, const float *head,
+                      const float *aux, const float *scores, const int32_t *count, const int32_t *column_tags,
+                      const int32_t *feat, int k, float *raw, float *acts, uint8_t *mask, float *top_values,
+                      int32_t *top_info, tsc_stream_t stream);
+
+/*
  * Scores of a few selected features for every token, without touching the other d_sae - F columns:
  *   out[m, j] = act( dot(x[m,:] - b_dec, Pt[j,:]) + bias[j] ),  act = ReLU if apply_relu else identity,
  * Pt [F, d_in] holds the selected encoder columns as rows (W_enc[:, feats] transposed), bias [F],

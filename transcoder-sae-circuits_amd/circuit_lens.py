@@ -293,7 +293,7 @@ def _pass_streams(dev, n: int = 4):
 
 
 def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want_recon: bool = True,
-                        screened: bool = True, row_bounds: Optional[torch.Tensor] = None):
+                        screened: bool = True, row_bounds: Optional[torch.Tensor] = None, then=None):
     """All dictionaries of ``encoders`` (a list) over their ``inputs`` (a list of ``[R, d_in]`` tensors, the
     same R for all) with ONE host synchronisation: the counts of every dictionary live in one tensor that is
     zeroed once, checked against the capacity once and copied to the host once, and the outputs of all
@@ -302,6 +302,8 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
     ``screened``: use the handles that screen the emit with the bf16 MFMA and recompute the candidates exactly in
     fp32 (``TSC_F32_SCREEN``, include/tsc_hip.h) -- the same fp32 results, several times faster at CircuitLens sizes;
     ``row_bounds [D]`` are the screens' row bounds (``tsc_hip.screen_row_bound``), computed here when not given.
+    ``then(feat, val, count, recon, scores)``: optional device-only continuation, launched before the counts are
+    read (its result is appended to the returned tuple).
     Returns ``(feat [D,R,cap], val [D,R,cap], count [D,R], recon [D,R,d_out] or None, scores [D,R,cap] or None,
     counts on host [D,R])``."""
     import tsc_hip
@@ -315,6 +317,7 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
     handles = [enc.device_dict(screened=screened) for enc in encoders]
     if screened and row_bounds is None:
         row_bounds = torch.stack([tsc_hip.screen_row_bound(x, enc.b_dec.detach()) for enc, x in zip(encoders, inputs)])
+    tail = None
     while True:
         feat = torch.empty(n_d, rows, cap, dtype=torch.int32, device=dev)
         val = torch.empty(n_d, rows, cap, dtype=torch.float32, device=dev)
@@ -342,9 +345,15 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
                                         "scores": scores[i] if scores is not None else None})
         for stream in side:
             main.wait_stream(stream)
+        # work that only consumes this pass's device buffers is queued BEFORE the host looks at the counts, so the
+        # GPU never drains in the middle of the pass; it is redone in the (rare) retry with a larger capacity
+        if then is not None:
+            tail = then(feat, val, count, recon, scores)
         counts_host = count.cpu()  # the one synchronisation of the pass
         worst = int(counts_host.max()) if counts_host.numel() else 0
         if worst <= cap:
+            if then is not None:
+                return feat, val, count, recon, scores, counts_host, tail
             return feat, val, count, recon, scores, counts_host
         if cap >= tsc_hip.LENS_PASS_MAX_ACTIVE:
             raise tsc_hip.TscError(f"a position has {worst} active features in one dictionary, above the "
@@ -793,7 +802,7 @@ class BatchedCircuitLens:
         encs, xs = self._encoders_and_inputs()
         dirs = None
         if directions is not None:
-            dirs = self._dictionary_directions(self._row_directions(directions))
+            dirs, _ = self._dictionary_directions(self._row_directions(directions))
         with torch.no_grad():
             out = run_dictionary_pass(encs, xs, self.max_active, dirs=dirs, screened=self.screened,
                                       row_bounds=self._row_bounds())
@@ -801,11 +810,14 @@ class BatchedCircuitLens:
             self._pass = out
         return out
 
-    def _dictionary_directions(self, d: torch.Tensor) -> torch.Tensor:
-        """``[D, R, d_out]``: row directions as each dictionary sees them (z-SAEs: pulled back through W_O)."""
-        n_layers = self.model.cfg.n_layers
+    def _dictionary_directions(self, d: torch.Tensor):
+        """Row directions as each dictionary sees them, one ``[R, d_out]`` tensor per dictionary (z-SAEs: pulled back
+        through W_O; every transcoder sees ``d`` itself -- no copy), and the stacked z directions ``[L, R, n*d]``."""
         dz = torch.matmul(d[None], self._tables()["w_o_t"])                       # [L, R, n*d]
-        return torch.stack([dz, d[None].expand(n_layers, -1, -1)], dim=1).reshape(2 * n_layers, *d.shape)
+        dirs = []
+        for layer in range(self.model.cfg.n_layers):
+            dirs += [dz[layer], d]
+        return dirs, dz
 
     def _row_directions(self, directions: torch.Tensor) -> torch.Tensor:
         d = directions.to(self.tokens.device, torch.float32)
@@ -837,73 +849,67 @@ class BatchedCircuitLens:
         return self.lens(index)
 
     # ------------------------------------------------------------------ batched direction lens
-    def direction_lens(self, directions: torch.Tensor, k: int = 10):
+    def direction_lens(self, directions: torch.Tensor, k: int = 10, dense: bool = True):
         """For every covered row: ``normalize_activations(vectors @ direction)`` of its ``ActiveFeatures`` without
         building the vectors, and its top-``k``.  Returns a dict of device tensors:
 
         ``activations [R, W]`` (padded column layout, 0 in padding), ``mask [R, W]``, ``top_values [R, k]`` and the
         identity of each winner ``top_component [R, k]`` (index into ``component_names``), ``top_layer [R, k]``,
         ``top_feature [R, k]`` (-1 on auxiliary rows); ``-inf`` / -1 where a row has fewer than k components.
-        Column layout per row = the ActiveFeatures row order with every feature block padded to the capacity."""
+        Column layout per row = the ActiveFeatures row order with every feature block padded to the capacity.
+        ``dense=False`` skips the three ``[R, W]`` outputs (``activations``, ``mask``, ``raw``).
+        The assembly, the normalisation and the ranking are ONE launch (``tsc_lens_assemble``), queued behind the
+        dictionaries before the host reads the counts; ties rank by column (the reference's ``topk`` leaves them open)."""
+        import tsc_hip
+
         d = self._row_directions(directions)
         encs, xs = self._encoders_and_inputs()
         with torch.no_grad():
-            dirs = self._dictionary_directions(d)
-            feat, val, count, recon, scores, counts_host = run_dictionary_pass(
-                encs, xs, self.max_active, dirs=dirs, screened=self.screened, row_bounds=self._row_bounds())
+            dirs, dz = self._dictionary_directions(d)
+            t = self._tables()
+            n_layers, rows = self.model.cfg.n_layers, self.n_rows
+
+            def tail(feat, val, count, recon, scores):
+                # (everything here is queued behind the dictionaries' launches: the host works while the GPU does)
+                head = torch.stack([(t["embed"] * d).sum(-1), (t["pos_embed"] * d).sum(-1)], dim=1).contiguous()
+                b_o = d @ t["b_o"].t()                                                    # [R, L]
+                z_bias = (t["z_b_dec"][:, None, :] * dz).sum(-1).t()
+                t_bias = d @ t["t_b_out"].t()
+                # auxiliary rows of every layer at once (row order of ActiveFeatures: b_O, z error, z bias | error, bias)
+                z_err = ((t["z"] - recon[0::2]) * dz).sum(-1).t()
+                t_err = ((t["mlp_out"] - recon[1::2]) * d[None]).sum(-1).t()
+                aux = torch.stack([b_o, z_err, z_bias, t_err, t_bias], dim=2).reshape(rows, -1).contiguous()  # [R, 5L]
+                return tsc_hip.lens_assemble(head, aux, [3, 2] * n_layers, scores, count, k=k, dense=dense,
+                                             column_tags=self._column_tags(d.device), feat=feat)
+
+            feat, val, count, recon, scores, counts_host, res = run_dictionary_pass(
+                encs, xs, self.max_active, dirs=dirs, screened=self.screened, row_bounds=self._row_bounds(), then=tail)
             if self._pass is None:
                 self._pass = (feat, val, count, recon, scores, counts_host)
-            t = self._tables()
-            n_layers, cap, rows = self.model.cfg.n_layers, feat.shape[2], self.n_rows
-            dev = d.device
-            dz = dirs[0::2]                                                               # [L, R, n*d]
-            # auxiliary rows of every layer at once (row order of ActiveFeatures: b_O, z error, z bias | error, bias)
-            b_o = d @ t["b_o"].t()                                                        # [R, L]
-            z_err = ((t["z"] - recon[0::2]) * dz).sum(-1).t()
-            z_bias = (t["z_b_dec"][:, None, :] * dz).sum(-1).t()
-            t_err = ((t["mlp_out"] - recon[1::2]) * d[None]).sum(-1).t()
-            t_bias = d @ t["t_b_out"].t()
-            per_layer = torch.cat([torch.stack([b_o, z_err, z_bias], dim=2), scores[0::2].permute(1, 0, 2),
-                                   torch.stack([t_err, t_bias], dim=2), scores[1::2].permute(1, 0, 2)], dim=2)  # [R, L, 5+2cap]
-            head = torch.stack([(t["embed"] * d).sum(-1), (t["pos_embed"] * d).sum(-1)], dim=1)
-            raw = torch.cat([head, per_layer.reshape(rows, -1)], dim=1)
-            slot = torch.arange(cap, device=dev)
-            live_z = slot[None, None, :] < count[0::2].t()[:, :, None]                    # [R, L, cap]
-            live_m = slot[None, None, :] < count[1::2].t()[:, :, None]
-            ones = torch.ones(rows, n_layers, 3, dtype=torch.bool, device=dev)
-            mask = torch.cat([ones[:, 0, :2], torch.cat([ones, live_z, ones[:, :, :2], live_m], dim=2).reshape(rows, -1)], dim=1)
-            raw = torch.where(mask, raw, torch.zeros_like(raw))
-            acts = raw / raw.sum(dim=1, keepdim=True)                                     # normalize_activations (:551-554)
-            ranked = torch.where(mask, acts, torch.full_like(acts, float("-inf")))
-            kk = min(k, ranked.shape[1])
-            top_v, top_c = ranked.topk(kk, dim=1)
-            comp_t, lay_t = self._column_tables(cap, dev)
-            minus3 = torch.full((rows, n_layers, 3), -1, dtype=torch.int32, device=dev)
-            fcols = torch.cat([minus3[:, 0, :2], torch.cat([minus3, feat[0::2].permute(1, 0, 2), minus3[:, :, :2],
-                                                            feat[1::2].permute(1, 0, 2)], dim=2).reshape(rows, -1)], dim=1)
-            live = torch.isfinite(top_v)
-            neg = torch.full_like(top_c, -1)
-            return {
-                "activations": acts, "mask": mask, "raw": raw, "top_values": top_v,
-                "top_component": torch.where(live, comp_t[top_c], neg),
-                "top_layer": torch.where(live, lay_t[top_c], neg),
-                "top_feature": torch.where(live, torch.gather(fcols, 1, top_c).long(), neg),
+            info = res["top_info"].long()  # [R, k, 4]: column, component, layer, feature (-1 where a row ran out)
+            out = {
+                "top_values": res["top_values"],
+                "top_component": info[:, :, 1], "top_layer": info[:, :, 2], "top_feature": info[:, :, 3],
                 "component_names": list(_COMPONENT_ORDER),
                 "row_prompt": self.row_prompt, "row_pos": self.row_pos,
             }
+            if dense:
+                out.update(activations=res["activations"], mask=res["mask"], raw=res["raw"])
+            return out
 
-    def _column_tables(self, cap: int, dev):
-        """Component kind and layer of every column of the padded layout (static per capacity)."""
-        key = (cap, str(dev))
-        cache = self.__dict__.setdefault("_col_tables", {})
-        if key not in cache:
+    def _column_tags(self, dev):
+        """``component << 16 | layer`` for every column class of the padded layout, in ``tsc_lens_assemble``'s order:
+        embed, pos_embed; per layer b_O, z error, z bias, transcoder error, transcoder bias; then one per dictionary."""
+        cache = self.__dict__.setdefault("_col_tags", {})
+        if str(dev) not in cache:
             n_layers = self.model.cfg.n_layers
-            comp, lay = [0, 1], [0, 0]
+            tags = [0 << 16, 1 << 16]
             for layer in range(n_layers):
-                comp += [2, 3, 4] + [5] * cap + [6, 7] + [8] * cap
-                lay += [layer] * (5 + 2 * cap)
-            cache[key] = (torch.tensor(comp, device=dev), torch.tensor(lay, device=dev))
-        return cache[key]
+                tags += [(c << 16) | layer for c in (2, 3, 4, 6, 7)]
+            for layer in range(n_layers):
+                tags += [(5 << 16) | layer, (8 << 16) | layer]
+            cache[str(dev)] = torch.tensor(tags, dtype=torch.int32, device=dev)
+        return cache[str(dev)]
 
     def direction_lens_runs(self, directions: torch.Tensor, k: int = 10) -> List[List[ComponentLensWithValue]]:
         """``direction_lens`` as the per-prompt lists the reference's lens functions return (one list per covered

@@ -364,6 +364,24 @@ int tsc_sparse_lens_pass(const tsc_dict_t *d, const float *x, int64_t M, int max
                                     dir_row_stride, recon, scores, nullptr, nullptr, nullptr, 0, s);
 }
 
+int tsc_lens_assemble(int64_t R, int n_head, int n_groups, const int32_t *group_aux, int max_active, const float *head,
+                      const float *aux, const float *scores, const int32_t *count, const int32_t *column_tags,
+                      const int32_t *feat, int k, float *raw, float *acts, uint8_t *mask, float *top_values,
+                      int32_t *top_info, tsc_stream_t stream) {
+    if (R < 0) return tsc_fail(TSC_ERR_ARG, "negative row count");
+    if (R == 0) return TSC_OK;
+    if (n_head < 0 || n_groups < 1 || !group_aux || max_active < 1 || k < 1 || k > 256)
+        return tsc_fail(TSC_ERR_ARG, "bad lens_assemble shape (n_head %d, n_groups %d, max_active %d, k %d)", n_head,
+                        n_groups, max_active, k);
+    if (!scores || !count || !top_values || !top_info || (n_head > 0 && !head))
+        return tsc_fail(TSC_ERR_ARG, "null lens_assemble pointer");
+    int n_aux = 0;
+    for (int g = 0; g < n_groups && g < 64; ++g) n_aux += group_aux[g] > 0 ? group_aux[g] : 0;
+    if (n_aux > 0 && !aux) return tsc_fail(TSC_ERR_ARG, "auxiliary scalars declared but aux is null");
+    return tsc_launch_lens_assemble(R, n_head, n_groups, group_aux, max_active, head, aux, scores, count, column_tags,
+                                    feat, k, raw, acts, mask, top_values, top_info, (hipStream_t)stream);
+}
+
 int tsc_decode_rows(const tsc_dict_t *d, const int32_t *feat, const float *val, int64_t n, float *rows,
                     tsc_stream_t stream) {
     int rc = check_decoder(d);

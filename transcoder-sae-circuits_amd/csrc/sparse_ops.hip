@@ -380,6 +380,242 @@ __global__ __launch_bounds__(256) void sparse_finish_kernel(const float *W_dec, 
     }
 }
 
+// The tail of the CircuitLens pass for a batch of rows, ONE launch: assemble each row's component scores in the
+// ActiveFeatures row order (head scalars, then per group its auxiliary scalars followed by the scores of its
+// dictionary's live features), divide by the row's sum (normalize_activations, reference src/circuit_lens.py:551-554)
+// and select the k largest (get_top_k_features, :161-164: `activations.topk(k)`).  grid = rows, block = 256.
+// Column layout of a row (W columns): [n_head] then for g < n_groups: [aux_n[g]] [cap score slots of dictionary g].
+// A score slot is live iff slot < count[g][row]; dead slots read 0 in raw / acts and never rank.
+// Selection order: value descending, column ascending (deterministic; torch.topk leaves ties unspecified); NaN
+// never ranks.  The row is kept in LDS when it fits (W <= lds_cols), else the rounds re-read `acts` (L2-hot).
+constexpr int ASM_MAX_GROUPS = 64;
+constexpr int ASM_CAND_MAX = 2048;  // selection candidates held in LDS
+constexpr int ASM_VPT = 60;  // ranked values a thread keeps in registers: rows of up to 256 * 60 = 15360 columns
+struct AssembleArgs {
+    long long R;
+    int n_head, n_groups, cap, W, k, n_aux_total, lds_cols;
+    int aux_n[ASM_MAX_GROUPS];      // auxiliary scalars in front of each group's score slots
+    int aux_off[ASM_MAX_GROUPS];    // offset of the group's auxiliary scalars in a row of `aux`
+    int col_off[ASM_MAX_GROUPS];    // first column of the group
+    const float *head, *aux, *scores;
+    const int *count;
+    const int *tags;   // optional [n_head + n_aux_total + n_groups]: the caller's label of every column class
+    const int *feat;   // optional [n_groups, R, cap]: the feature id behind every score slot
+    float *raw, *acts;
+    unsigned char *mask;
+    float *top_v;
+    int *top_info;     // [R, k, 4]: column, tag >> 16, tag & 0xffff, feature id
+};
+
+__global__ __launch_bounds__(256) void lens_assemble_kernel(const AssembleArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *row = (float *)smem_raw;  // [lds_cols] ranked values (dead = -inf) when the row fits
+    __shared__ float red_v[4];
+    __shared__ int red_c[4];
+    __shared__ float s_total;
+    __shared__ int s_cnt[ASM_MAX_GROUPS], s_col[ASM_MAX_GROUPS], s_aux[ASM_MAX_GROUPS], s_aoff[ASM_MAX_GROUPS];
+    __shared__ float m_v[256], cand_v[ASM_CAND_MAX], t_v;
+    __shared__ int m_c[256], cand_c[ASM_CAND_MAX], t_c, n_cand;
+    const long long r = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool in_lds = p.W <= p.lds_cols;
+    const float NINF = -__builtin_inff();
+    float *raw_row = p.raw ? p.raw + r * p.W : nullptr;
+    float *acts_row = p.acts ? p.acts + r * p.W : nullptr;
+    unsigned char *mask_row = p.mask ? p.mask + r * p.W : nullptr;
+    // pass 1, group by group (the group index is uniform: its tables stay in scalar registers, the score slots are
+    // read coalesced): raw values, mask, the row sum in a fixed order
+    float part = 0.f;
+    auto put = [&](int c, float v, bool live) {
+        part += v;
+        if (raw_row) raw_row[c] = v;
+        if (mask_row) mask_row[c] = live ? 1 : 0;
+        if (in_lds) row[c] = live ? v : NINF;  // the raw value for now; scaled in pass 2
+    };
+    if (tid < p.n_groups) {
+        const int cnt = p.count[(long long)tid * p.R + r];
+        s_cnt[tid] = cnt > p.cap ? p.cap : cnt;
+        s_col[tid] = p.col_off[tid];
+        s_aux[tid] = p.aux_n[tid];
+        s_aoff[tid] = p.aux_off[tid];
+    }
+    __syncthreads();
+    // what the caller wants to know about a winning column: its class label and the feature behind a score slot
+    auto emit = [&](int j, float v, int c) {
+        int tag = -1, feature = -1;
+        if (c >= 0) {
+            int cls;  // index into tags: head columns, then the auxiliary scalars group after group, then one per group
+            if (c < p.n_head) cls = c;
+            else {
+                int g = 0;
+                while (g + 1 < p.n_groups && c >= s_col[g + 1]) ++g;
+                const int o = c - s_col[g];
+                if (o < s_aux[g]) cls = p.n_head + s_aoff[g] + o;
+                else {
+                    cls = p.n_head + p.n_aux_total + g;
+                    if (p.feat) feature = p.feat[((long long)g * p.R + r) * p.cap + (o - s_aux[g])];
+                }
+            }
+            if (p.tags) tag = p.tags[cls];
+        }
+        int *info = p.top_info + (r * p.k + j) * 4;
+        p.top_v[r * p.k + j] = v;
+        info[0] = c;
+        info[1] = tag < 0 ? -1 : tag >> 16;
+        info[2] = tag < 0 ? -1 : tag & 0xffff;
+        info[3] = feature;
+    };
+    if (tid < p.n_head) put(tid, p.head[r * p.n_head + tid], true);
+    for (int g = 0; g < p.n_groups; ++g)
+        if (tid < p.aux_n[g]) put(p.col_off[g] + tid, p.aux[r * p.n_aux_total + p.aux_off[g] + tid], true);
+    // score slots: eight groups' loads in flight before the first store (the stores would otherwise serialise one
+    // load round trip per group: nothing tells the compiler that the outputs do not alias the scores)
+    const float *__restrict__ sc = p.scores + r * p.cap;
+    const long long gstride = p.R * p.cap;
+    for (int slot = tid; slot < p.cap; slot += 256)
+        for (int g0 = 0; g0 < p.n_groups; g0 += 8) {
+            float v[8];
+            bool live[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int g = g0 + u < p.n_groups ? g0 + u : p.n_groups - 1;
+                live[u] = slot < s_cnt[g];
+                v[u] = sc[g * gstride + slot];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (g0 + u < p.n_groups) put(p.col_off[g0 + u] + p.aux_n[g0 + u] + slot, live[u] ? v[u] : 0.f, live[u]);
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) red_v[wave] = part;
+    __syncthreads();
+    if (tid == 0) s_total = (red_v[0] + red_v[1]) + (red_v[2] + red_v[3]);
+    __syncthreads();
+    const float total = s_total;
+    // pass 2: acts = raw / total (a division, as the reference divides).  Columns are walked with stride 256 from
+    // here on: column c belongs to thread c & 255, which keeps its ranked values (dead = -inf) in REGISTERS when the
+    // row went through LDS (W <= 256 * ASM_VPT) -- the k selection rounds then touch no memory.
+    float vals[ASM_VPT];
+    float bv = NINF;
+    int bc = 0x7fffffff;
+    if (in_lds) {
+#pragma unroll
+        for (int i = 0; i < ASM_VPT; ++i) {
+            const int c = tid + 256 * i;
+            vals[i] = NINF;
+            if (c < p.W) {
+                const float v = row[c];
+                const bool live = v != NINF;
+                const float a = live ? v / total : 0.f;
+                if (acts_row) acts_row[c] = a;
+                if (live) vals[i] = a;
+                if (live && a > bv) { bv = a; bc = c; }  // ascending c: the first of equal values stays
+            }
+        }
+    } else {  // rows too wide for LDS: the launcher insists on raw, acts and mask, and the rounds re-read them
+        for (int c = tid; c < p.W; c += 256) {
+            const bool live = mask_row[c] != 0;
+            const float a = live ? raw_row[c] / total : 0.f;
+            acts_row[c] = a;
+            if (live && a > bv) { bv = a; bc = c; }
+        }
+    }
+    // Selection without k serial block-wide rounds.  An element of the global top-k can only belong to one of the k
+    // threads with the largest per-thread maxima, and must rank at or above the k-th largest of those maxima (T):
+    // those threads push their qualifying elements (typically a dozen or two in total) into an LDS list, which is
+    // then rank-sorted in one step.  Order everywhere: value descending, column ascending.
+    if (tid < p.k) emit(tid, NINF, -1);
+    m_v[tid] = bv;
+    m_c[tid] = bc;
+    if (tid == 0) { n_cand = 0; t_v = NINF; t_c = 0x7fffffff; }
+    __syncthreads();
+    {
+        int rank = 0;
+        for (int i = 0; i < 256; ++i) {
+            const float ov = m_v[i];
+            const int oc = m_c[i];
+            rank += (ov > bv || (ov == bv && oc < bc)) ? 1 : 0;
+        }
+        const bool has = bv > NINF;
+        if (has && rank == p.k - 1) { t_v = bv; t_c = bc; }  // fewer than k live threads: T stays "everything qualifies"
+        __syncthreads();
+        const float tv = t_v;
+        const int tc = t_c;
+        if (has && rank < p.k) {
+            auto push = [&](float v, int c) {
+                if (v > NINF && (v > tv || (v == tv && c <= tc))) {
+                    const int pos = atomicAdd(&n_cand, 1);
+                    if (pos < ASM_CAND_MAX) { cand_v[pos] = v; cand_c[pos] = c; }
+                }
+            };
+            if (in_lds) {
+#pragma unroll
+                for (int i = 0; i < ASM_VPT; ++i) push(vals[i], tid + 256 * i);
+            } else {
+                for (int c = tid; c < p.W; c += 256) push(mask_row[c] ? acts_row[c] : NINF, c);
+            }
+        }
+        __syncthreads();
+    }
+    const int n = n_cand;
+    if (n <= ASM_CAND_MAX) {
+        for (int e = tid; e < n; e += 256) {
+            const float v = cand_v[e];
+            const int c = cand_c[e];
+            int rank = 0;
+            for (int i = 0; i < n; ++i) {
+                const float ov = cand_v[i];
+                const int oc = cand_c[i];
+                rank += (ov > v || (ov == v && oc < c)) ? 1 : 0;
+            }
+            if (rank < p.k) emit(rank, v, c);
+        }
+        return;
+    }
+    // (more candidates than the list holds -- k * columns-per-thread can exceed it for wide rows and large k --:)
+    // k rounds: block-wide best of the threads' candidates; only the winner's thread looks for its next one (the
+    // others' candidates are still their best below the new winner)
+    for (int j = 0; j < p.k; ++j) {
+        float wv = bv;
+        int wc = bc;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(wv, off);
+            const int oc = __shfl_xor(wc, off);
+            if (ov > wv || (ov == wv && oc < wc)) { wv = ov; wc = oc; }
+        }
+        if (lane == 0) { red_v[wave] = wv; red_c[wave] = wc; }
+        __syncthreads();
+        wv = red_v[0]; wc = red_c[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (red_v[w] > wv || (red_v[w] == wv && red_c[w] < wc)) { wv = red_v[w]; wc = red_c[w]; }
+        __syncthreads();
+        const bool found = wc != 0x7fffffff;
+        if (!found) break;  // fewer than k live columns: the rest stay empty (pre-filled above)
+        if (tid == 0) emit(j, wv, wc);
+        if ((wc & 255) == tid) {  // my candidate won: my largest (value, -column) strictly below it
+            bv = NINF; bc = 0x7fffffff;
+            if (in_lds) {
+#pragma unroll
+                for (int i = 0; i < ASM_VPT; ++i) {
+                    const int c = tid + 256 * i;
+                    const float v = vals[i];
+                    const bool below = v < wv || (v == wv && c > wc);
+                    if (below && v > bv) { bv = v; bc = c; }
+                }
+            } else {
+                for (int c = tid; c < p.W; c += 256) {
+                    const float v = mask_row[c] ? acts_row[c] : NINF;
+                    const bool below = v < wv || (v == wv && c > wc);
+                    if (below && v > bv) { bv = v; bc = c; }
+                }
+            }
+        }
+    }
+}
+
 // one wavefront per token row: the row (minus b_dec) is held in registers, each selected encoder
 // column (a contiguous row of Pt, L2-resident) is dotted against it
 __global__ __launch_bounds__(256) void project_kernel(const float *x, long long M, int d_in, const float *b_dec,
@@ -500,6 +736,38 @@ int tsc_launch_sparse_finish(const float *W_dec, const float *bias, int d_out, i
         hipLaunchKernelGGL(sparse_finish_kernel<false>, dim3((unsigned)M), dim3(256), 0, stream, W_dec, bias, d_out, feat,
                            val, count, max_active, dirs, dir_stride, recon, scores, x, W_enc_t, bias_fold, d_in);
     }
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
+int tsc_launch_lens_assemble(long long R, int n_head, int n_groups, const int *group_aux, int cap, const float *head,
+                             const float *aux, const float *scores, const int *count, const int *tags, const int *feat,
+                             int k, float *raw, float *acts, unsigned char *mask, float *top_v, int *top_info,
+                             hipStream_t stream) {
+    if (R <= 0) return TSC_OK;
+    if (n_groups < 1 || n_groups > ASM_MAX_GROUPS)
+        return tsc_fail(TSC_ERR_UNSUPPORTED, "lens assemble takes 1..%d groups (got %d)", ASM_MAX_GROUPS, n_groups);
+    if (n_head > 256) return tsc_fail(TSC_ERR_UNSUPPORTED, "lens assemble takes at most 256 head scalars (got %d)", n_head);
+    AssembleArgs p;
+    p.R = R; p.n_head = n_head; p.n_groups = n_groups; p.cap = cap; p.k = k;
+    int col = n_head, aoff = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        if (group_aux[g] < 0 || group_aux[g] > 256)
+            return tsc_fail(TSC_ERR_ARG, "auxiliary count of group %d outside 0..256", g);
+        p.aux_n[g] = group_aux[g]; p.aux_off[g] = aoff; p.col_off[g] = col;
+        aoff += group_aux[g];
+        col += group_aux[g] + cap;
+    }
+    for (int g = n_groups; g < ASM_MAX_GROUPS; ++g) p.aux_n[g] = p.aux_off[g] = p.col_off[g] = 0;
+    p.W = col; p.n_aux_total = aoff;
+    p.lds_cols = 15 * 1024;  // 60 KiB of dynamic LDS: two workgroups per CU
+    p.head = head; p.aux = aux; p.scores = scores; p.count = count;
+    p.tags = tags; p.feat = feat;
+    p.raw = raw; p.acts = acts; p.mask = mask; p.top_v = top_v; p.top_info = top_info;
+    if (p.W > p.lds_cols && (!acts || !raw || !mask))
+        return tsc_fail(TSC_ERR_UNSUPPORTED, "lens assemble: rows of %d columns do not fit in LDS, pass the raw, acts and mask outputs", p.W);
+    const size_t lds = p.W <= p.lds_cols ? (size_t)p.W * sizeof(float) : 16;
+    hipLaunchKernelGGL(lens_assemble_kernel, dim3((unsigned)R), dim3(256), lds, stream, p);
     TSC_HIP_CHECK(hipGetLastError());
     return TSC_OK;
 }

@@ -98,6 +98,10 @@ int tsc_launch_contrib(const float *W_dec, int d_out, const int *feat, const flo
                        const int *count, long long M, int max_active, const float *dirs, int n_dir,
                        float *scores, hipStream_t stream);
 int tsc_sparse_finish_supported(int d_out, int max_active);
+int tsc_launch_lens_assemble(long long R, int n_head, int n_groups, const int *group_aux, int cap, const float *head,
+                             const float *aux, const float *scores, const int *count, const int *tags, const int *feat,
+                             int k, float *raw, float *acts, unsigned char *mask, float *top_v, int *top_info,
+                             hipStream_t stream);
 int tsc_launch_sparse_finish(const float *W_dec, const float *bias, int d_out, int *feat, float *val, int *count,
                              long long M, int max_active, const float *dirs, long long dir_stride, float *recon,
                              float *scores, const float *x, const float *W_enc_t, const float *bias_fold, int d_in,

@@ -55,6 +55,9 @@ _SIGNATURES = {
     "tsc_sparse_lens_pass": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p,
                                         _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p,
                                         _c.c_void_p, _c.c_void_p]),
+    "tsc_lens_assemble": (_c.c_int, [_c.c_int64, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                     _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
+                                     _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "tsc_project_features": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                         _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
 }
@@ -334,6 +337,51 @@ def screen_row_bound(x: torch.Tensor, b_dec: torch.Tensor) -> torch.Tensor:
     centred = (x - b_dec.unsqueeze(-2)).norm(dim=-1).amax(dim=-1)
     raw = x.norm(dim=-1).amax(dim=-1)
     return (((2.0 ** -8 * 1.01 + g) * centred + g * (raw + b_dec.norm(dim=-1))) * 1.0001).to(torch.float32).contiguous()
+
+
+def lens_assemble(head: torch.Tensor, aux: torch.Tensor, group_aux, scores: torch.Tensor, count: torch.Tensor,
+                  k: int = 10, dense: bool = True, column_tags: Optional[torch.Tensor] = None,
+                  feat: Optional[torch.Tensor] = None):
+    """``tsc_lens_assemble``: normalise-and-rank tail of the CircuitLens pass for ``R`` rows in one launch.
+    ``head [R, n_head]``, ``aux [R, sum(group_aux)]``, ``scores [G, R, cap]``, ``count [G, R]`` (int32); optional
+    ``column_tags [n_head + sum(group_aux) + G]`` (int32 labels of the column classes) and ``feat [G, R, cap]``.
+    Returns ``{"raw", "activations", "mask"}`` (``[R, W]``, only when ``dense``) plus ``top_values [R, k]``,
+    ``top_info [R, k, 4]`` (int32: column, tag >> 16, tag & 0xffff, feature id) and its view ``top_columns``
+    (-inf / -1 where a row has fewer than k live columns)."""
+    scores = _dev(scores, torch.float32, "scores")
+    count = _dev(count, torch.int32, "count")
+    G, R, cap = scores.shape
+    head = _dev(head.reshape(R, -1), torch.float32, "head")
+    aux = _dev(aux.reshape(R, -1), torch.float32, "aux")
+    group_aux = [int(a) for a in group_aux]
+    if len(group_aux) != G or aux.shape[1] != sum(group_aux) or tuple(count.shape) != (G, R):
+        raise TscError("lens_assemble: group_aux / aux / count do not match scores [G, R, cap]")
+    if column_tags is not None:
+        column_tags = _dev(column_tags, torch.int32, "column_tags")
+        if column_tags.numel() != head.shape[1] + sum(group_aux) + G:
+            raise TscError("lens_assemble: column_tags needs one entry per head scalar, auxiliary scalar and group")
+    if feat is not None:
+        feat = _dev(feat, torch.int32, "feat")
+        if tuple(feat.shape) != (G, R, cap):
+            raise TscError("lens_assemble: feat must be [G, R, cap] like scores")
+    W = head.shape[1] + sum(group_aux) + G * cap
+    dev = scores.device
+    out = {"top_values": torch.empty(R, k, dtype=torch.float32, device=dev),
+           "top_info": torch.empty(R, k, 4, dtype=torch.int32, device=dev)}
+    if dense or W > 15360:  # rows that do not fit in LDS are ranked out of the dense outputs
+        out["activations"] = torch.empty(R, W, dtype=torch.float32, device=dev)
+        out["raw"] = torch.empty(R, W, dtype=torch.float32, device=dev)
+        out["mask"] = torch.empty(R, W, dtype=torch.bool, device=dev)
+    ga = (ctypes.c_int32 * G)(*group_aux)
+    ptr = lambda n: out[n].data_ptr() if n in out else None  # noqa: E731
+    _check(lib().tsc_lens_assemble(R, head.shape[1], G, ga, cap, head.data_ptr() if head.numel() else None,
+                                   aux.data_ptr() if aux.numel() else None, scores.data_ptr(), count.data_ptr(),
+                                   column_tags.data_ptr() if column_tags is not None else None,
+                                   feat.data_ptr() if feat is not None else None, k,
+                                   ptr("raw"), ptr("activations"), ptr("mask"), out["top_values"].data_ptr(),
+                                   out["top_info"].data_ptr(), _stream()))
+    out["top_columns"] = out["top_info"][:, :, 0]
+    return out
 
 
 class TopkState:
