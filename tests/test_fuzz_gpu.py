@@ -1,0 +1,19 @@
+"""A few seconds of the randomised comparisons in ``tools/`` (shapes, list lengths, slot counts, staging variants,
+duplicated rows that the fixed tests do not enumerate): the fused top-k against the exact ranking of the library's own
+dense activations, and the bf16-screened top-k against the fp32 one, bit for bit."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("tool,seed", [("fuzz_topk.py", 11), ("fuzz_screened.py", 12)])
+def test_randomised_list_checks(tool, seed):
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tools", tool), "4", str(seed)], capture_output=True,
+                       text=True, timeout=110)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    assert p.stdout.strip().splitlines()[-1].startswith("ok:")
