@@ -1,6 +1,7 @@
 """A few seconds of the randomised comparisons in ``tools/`` (shapes, list lengths, slot counts, staging variants,
 duplicated rows that the fixed tests do not enumerate): the fused top-k against the exact ranking of the library's own
-dense activations, and the bf16-screened top-k against the fp32 one, bit for bit."""
+dense activations, the bf16-screened top-k against the fp32 one, bit for bit, and the lens pass (plain: exactly the
+sorted positives of the dense activations; screened: no active feature above the fp32 rounding noise lost or invented)."""
 import os
 import subprocess
 import sys
@@ -11,7 +12,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,seed", [("fuzz_topk.py", 11), ("fuzz_screened.py", 12)])
+@pytest.mark.parametrize("tool,seed", [("fuzz_topk.py", 11), ("fuzz_screened.py", 12), ("fuzz_lens.py", 13)])
 def test_randomised_list_checks(tool, seed):
     p = subprocess.run([sys.executable, os.path.join(REPO, "tools", tool), "4", str(seed)], capture_output=True,
                        text=True, timeout=110)
