@@ -88,11 +88,14 @@ def test_encode_dense_odd_shapes():
 
 
 @pytest.mark.parametrize("d_in,d_sae,bf16", [(64, 1000, False), (768, 1000, False), (192, 132, False),
-                                             (128, 200, True), (768, 1000, True), (96, 260, False)])
+                                             (128, 200, True), (768, 1000, True), (96, 260, False),
+                                             (4, 4, False), (8, 132, False), (28, 260, False), (36, 8, False)])
 def test_all_epilogues_on_ragged_dictionary_shapes(d_in, d_sae, bf16):
     """Shapes that exercise the tails of every kernel variant: d_sae not a multiple of the 128-wide
     column tile (clamped W rows, masked columns), the shortest k-loops of the LDS-DMA kernels
-    (d_in = 64 / 128), a d_in that falls back to register staging (96), ragged token tiles."""
+    (d_in = 64 / 128), a d_in that falls back to register staging (96), ragged token tiles, and the smallest
+    legal shapes (d_in < 32: a whole k-step of clamped x columns -- a 32-bit offset once went negative there and
+    the load faulted; d_sae = 4: one partial column tile)."""
     import tsc_hip
     from standins.synthetic_dicts import make_dictionary_weights
 

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
             const char *xt = (const char *)(a.x + m0 * a.K);
 #pragma unroll
             for (int i = 0; i < C::A_LD; ++i)
-                ra[i] = *(const f32x4 *)(xt + a_voff[i] + (unsigned)(kc - a_col) * 4u);
+                ra[i] = *(const f32x4 *)(xt + a_voff[i] + (long long)(kc - a_col) * 4);  // kc < a_col when K < 32: signed
             const char *wt = (const char *)a.W;
 #pragma unroll
             for (int i = 0; i < C::B_LD; ++i) {
