@@ -31,16 +31,16 @@ def fail(msg):
 
 
 while time.time() - t0 < budget:
-    d_in = [128, 256, 768][ri(0, 2)]
-    d_sae = [260, 1536, 4100, 24576][ri(0, 3)]
-    d_out = [64, 256, 768][ri(0, 2)]
+    d_in = [4, 36, 128, 256, 768][ri(0, 4)]
+    d_sae = [4, 8, 260, 1536, 4100, 24576][ri(0, 5)]
+    d_out = [4, 8, 64, 256, 768][ri(0, 4)]
     m = [1, 5, 130, 512, 1000][ri(0, 4)]
     scale = [1.0, 1e-2, 20.0][ri(0, 2)]
     bdec_scale = [0.0, 0.1, 4.0][ri(0, 2)]
     gd = torch.Generator(device=dev).manual_seed(seed * 7919 + n_cases)
     W = (torch.randn(d_in, d_sae, generator=gd, device=dev) / d_in ** 0.5).contiguous()
     b_dec = torch.randn(d_in, generator=gd, device=dev) * bdec_scale * scale
-    b_enc = -(torch.rand(d_sae, generator=gd, device=dev) * 1.0 + 1.8) * scale      # a percent or two of the features fire
+    b_enc = -(torch.rand(d_sae, generator=gd, device=dev) * 1.0 + (1.8 if d_sae > 64 else 0.0)) * scale  # a percent or two of the features fire (more in tiny dictionaries)
     W_dec = torch.randn(d_sae, d_out, generator=gd, device=dev).contiguous()
     out_bias = torch.randn(d_out, generator=gd, device=dev)
     x = torch.randn(m, d_in, generator=gd, device=dev) * scale * (0.2 + 2.8 * torch.rand(m, 1, generator=gd, device=dev))

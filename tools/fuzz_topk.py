@@ -39,8 +39,8 @@ def rank(acts, k, base):
 
 
 while time.time() - t0 < budget:
-    d_in = [36, 100, 128, 192, 256, 768, 772, 1024][ri(0, 7)]
-    d_sae = [132, 260, 1536, 4100, 6144, 24576][ri(0, 5)]
+    d_in = [4, 8, 28, 36, 100, 128, 192, 256, 768, 772, 1024][ri(0, 10)]
+    d_sae = [4, 8, 132, 260, 1536, 4100, 6144, 24576][ri(0, 7)]
     k = [1, 5, 20, 33, 64][ri(0, 4)]
     n_slots = [1, 2, 3, 4, 8][ri(0, 4)]
     bf16 = d_in % 128 == 0 and ri(0, 2) == 0
