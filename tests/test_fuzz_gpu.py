@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,seed", [("fuzz_topk.py", 11), ("fuzz_screened.py", 12), ("fuzz_lens.py", 13), ("fuzz_merge.py", 14), ("fuzz_encode.py", 15)])
+@pytest.mark.parametrize("tool,seed", [("fuzz_topk.py", 11), ("fuzz_screened.py", 12), ("fuzz_lens.py", 13), ("fuzz_merge.py", 14), ("fuzz_encode.py", 15), ("fuzz_aux.py", 16)])
 def test_randomised_list_checks(tool, seed):
     p = subprocess.run([sys.executable, os.path.join(REPO, "tools", tool), "4", str(seed)], capture_output=True,
                        text=True, timeout=110)
