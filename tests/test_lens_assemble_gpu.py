@@ -147,3 +147,11 @@ def test_lens_assemble_argument_errors():
     with pytest.raises(tsc_hip.TscError):
         tsc_hip.lens_assemble(torch.zeros(4, 2, device=DEV), torch.zeros(4, 130, device=DEV), [1] * 65,
                               torch.zeros(65, 4, 8, device=DEV), torch.zeros(65, 4, dtype=torch.int32, device=DEV))
+
+
+def test_lens_assemble_zero_rows():
+    import tsc_hip
+
+    out = tsc_hip.lens_assemble(torch.zeros(0, 2, device=DEV), torch.zeros(0, 2, device=DEV), [1, 1],
+                                torch.zeros(2, 0, 8, device=DEV), torch.zeros(2, 0, dtype=torch.int32, device=DEV), k=3)
+    assert out["top_values"].shape == (0, 3) and out["top_info"].shape == (0, 3, 4) and out["activations"].shape == (0, 20)
