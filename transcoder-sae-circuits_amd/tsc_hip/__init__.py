@@ -352,8 +352,8 @@ def lens_assemble(head: torch.Tensor, aux: torch.Tensor, group_aux, scores: torc
     count = _dev(count, torch.int32, "count")
     G, R, cap = scores.shape
     group_aux = [int(a) for a in group_aux]
-    head = _dev(head.reshape(R, head.numel() // R if R else 0), torch.float32, "head")
-    aux = _dev(aux.reshape(R, sum(group_aux)), torch.float32, "aux")
+    head = _dev(head.reshape(R, -1) if R else head.reshape(0, head.shape[-1] if head.dim() > 1 else 0), torch.float32, "head")
+    aux = _dev(aux.reshape(R, -1) if R else aux.reshape(0, sum(group_aux)), torch.float32, "aux")
     if len(group_aux) != G or aux.shape[1] != sum(group_aux) or tuple(count.shape) != (G, R):
         raise TscError("lens_assemble: group_aux / aux / count do not match scores [G, R, cap]")
     if column_tags is not None:
