@@ -29,8 +29,9 @@ def fail(msg):
     sys.exit(1)
 
 
-def close(a, b, what, rtol=2e-5):
-    scale = float(b.abs().max()) + 1e-30
+def close(a, b, what, rtol=2e-5, scale=None):
+    # scale: the magnitude of the summed terms (a sum that cancels is only accurate relative to those)
+    scale = (float(b.abs().max()) if scale is None else float(scale)) + 1e-30
     err = float((a.double() - b.double()).abs().max())
     if err > rtol * scale + 1e-7:
         fail(f"{what}: error {err:.3e} at scale {scale:.3e}")
@@ -80,14 +81,16 @@ while time.time() - t0 < budget:
             exp = torch.where(((bad >= 0) & (bad < d_sae))[:, None], W_dec[bad.clamp(0, d_sae - 1).long()].double() * val.reshape(-1).double()[:, None], torch.zeros(1, dtype=torch.float64, device=dev))
             close(d.decode_rows(bad, val.reshape(-1)), exp, f"decode_rows d_sae {d_sae} d_out {d_out}")
             if d_out <= 4096:
-                close(d.decode_sparse(feat, val, count), rows.sum(1) + (ob.double() if ob is not None else 0), f"decode_sparse d_out {d_out} cap {cap}")
+                close(d.decode_sparse(feat, val, count), rows.sum(1) + (ob.double() if ob is not None else 0), f"decode_sparse d_out {d_out} cap {cap}",
+                      scale=(rows.abs().sum(1) + (ob.double().abs() if ob is not None else 0)).max())
         else:
             n_dir = ri(1, 8)
             if n_dir * d_out * 4 > 60 * 1024:
                 n_dir = 1
             dirs = torch.randn(n_dir, d_out, generator=gd, device=dev)
             exp = torch.einsum("mcd,nd->mcn", rows, dirs.double())
-            close(d.contrib_scores(feat, val, count, dirs), exp, f"contrib_scores n_dir {n_dir} d_out {d_out}", rtol=5e-5)
+            mag = torch.einsum("mcd,nd->mcn", rows.abs(), dirs.double().abs()).max()
+            close(d.contrib_scores(feat, val, count, dirs), exp, f"contrib_scores n_dir {n_dir} d_out {d_out}", rtol=1e-5, scale=mag)
         d.close()
     else:  # lens_assemble on a random layout
         G = ri(1, 24)
