@@ -12,9 +12,12 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,seed", [("fuzz_topk.py", 11), ("fuzz_screened.py", 12), ("fuzz_lens.py", 13), ("fuzz_merge.py", 14), ("fuzz_encode.py", 15), ("fuzz_aux.py", 16)])
-def test_randomised_list_checks(tool, seed):
-    p = subprocess.run([sys.executable, os.path.join(REPO, "tools", tool), "4", str(seed)], capture_output=True,
-                       text=True, timeout=110)
+@pytest.mark.parametrize("tool,seed,cases", [("fuzz_topk.py", 11, 500), ("fuzz_screened.py", 12, 150), ("fuzz_lens.py", 13, 300),
+                                             ("fuzz_merge.py", 14, 500), ("fuzz_encode.py", 15, 1000), ("fuzz_aux.py", 16, 1000)])
+def test_randomised_list_checks(tool, seed, cases):
+    """A fixed number of cases from a fixed seed (the same cases on every machine); the time budget is only a guard."""
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tools", tool), "90", str(seed), str(cases)],
+                       capture_output=True, text=True, timeout=115)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
-    assert p.stdout.strip().splitlines()[-1].startswith("ok:")
+    last = p.stdout.strip().splitlines()[-1]
+    assert last.startswith("ok:") and f"{cases} cases" in last, last

@@ -2,7 +2,7 @@
 """Randomised checks of the small entry points against fp64 torch restatements: tsc_project_features /
 FeatureProjector (both routes), tsc_decode_rows (padding ids -1 and out-of-range ids decode to zero),
 tsc_decode_sparse, tsc_contrib_scores (1..8 directions) and tsc_lens_assemble (random layouts).
-Usage: fuzz_aux.py [seconds] [seed]"""
+Usage: fuzz_aux.py [seconds] [seed] [max cases]"""
 import os
 import sys
 import time
@@ -15,6 +15,7 @@ import tsc_hip  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 60  # stop after this many cases (a deterministic run)
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(seed)
 t0, n_cases = time.time(), 0
@@ -37,7 +38,7 @@ def close(a, b, what, rtol=2e-5, scale=None):
         fail(f"{what}: error {err:.3e} at scale {scale:.3e}")
 
 
-while time.time() - t0 < budget:
+while time.time() - t0 < budget and n_cases < max_cases:
     gd = torch.Generator(device=dev).manual_seed(seed * 32452843 + n_cases)
     kind = ri(0, 3)
     if kind == 0:  # selected-feature projection

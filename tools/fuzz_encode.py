@@ -3,7 +3,7 @@
 formula relu((x - b_dec) @ W_enc + b_enc) (src/mlp_transcoder.py:194-213, src/z_sae.py:73-77): fp32 handles within
 1e-4 relative of the largest term magnitude (the north star's tolerance), bf16 handles within 2^-7 of the restatement
 on bf16-rounded operands.  Every staging variant (d_in 4 ... 1028), odd widths, ragged row counts, row scales.
-Usage: fuzz_encode.py [seconds] [seed]"""
+Usage: fuzz_encode.py [seconds] [seed] [max cases]"""
 import os
 import sys
 import time
@@ -16,6 +16,7 @@ import tsc_hip  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 60  # stop after this many cases (a deterministic run)
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(seed)
 t0, n_cases, worst32, worst16 = time.time(), 0, 0.0, 0.0
@@ -25,7 +26,7 @@ def ri(lo, hi):
     return int(torch.randint(lo, hi + 1, (1,), generator=g))
 
 
-while time.time() - t0 < budget:
+while time.time() - t0 < budget and n_cases < max_cases:
     d_in = [4, 36, 64, 100, 128, 192, 256, 768, 772, 1028][ri(0, 9)]
     d_sae = [4, 132, 260, 1536, 4100, 24576][ri(0, 5)]
     m = [1, 3, 127, 128, 129, 255, 257, 1000, 4097][ri(0, 8)]

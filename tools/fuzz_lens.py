@@ -3,7 +3,7 @@
 the positives of the library's own dense activations, value-descending, and recon / scores agree with a torch
 restatement on them; (2) TSC_F32_SCREEN handles -- the bf16 screen + exact recompute loses no feature whose fp32
 activation is above the rounding noise of the two summation orders, and invents none.  Random shapes, bias scales,
-row scales, b_dec magnitudes (the screen's error bound is what is under test).  Usage: fuzz_lens.py [seconds] [seed]"""
+row scales, b_dec magnitudes (the screen's error bound is what is under test).  Usage: fuzz_lens.py [seconds] [seed] [max cases]"""
 import os
 import sys
 import time
@@ -16,6 +16,7 @@ import tsc_hip  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 60  # stop after this many cases (a deterministic run)
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(seed)
 t0, n_cases, n_active = time.time(), 0, 0
@@ -30,7 +31,7 @@ def fail(msg):
     sys.exit(1)
 
 
-while time.time() - t0 < budget:
+while time.time() - t0 < budget and n_cases < max_cases:
     d_in = [4, 36, 128, 256, 768][ri(0, 4)]
     d_sae = [4, 8, 260, 1536, 4100, 24576][ri(0, 5)]
     d_out = [4, 8, 64, 256, 768][ri(0, 4)]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised check of tsc_topk_merge (the all-gather merge of config 3 and tsc_topk_finalize's engine) against an
 exact torch merge: n_lists 1..64, k 1..64 (n_lists * k <= 2048), odd d_sae, lists of every fill level (padding: value
-0 / id -1), exact value ties across lists (token ids decide), int64 ids beyond 2^32.  Usage: fuzz_merge.py [seconds] [seed]"""
+0 / id -1), exact value ties across lists (token ids decide), int64 ids beyond 2^32.  Usage: fuzz_merge.py [seconds] [seed] [max cases]"""
 import os
 import sys
 import time
@@ -14,6 +14,7 @@ import tsc_hip  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 60  # stop after this many cases (a deterministic run)
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(seed)
 t0, n_cases = time.time(), 0
@@ -23,7 +24,7 @@ def ri(lo, hi):
     return int(torch.randint(lo, hi + 1, (1,), generator=g))
 
 
-while time.time() - t0 < budget:
+while time.time() - t0 < budget and n_cases < max_cases:
     k = [1, 2, 5, 20, 33, 64][ri(0, 5)]
     n_lists = min([1, 2, 3, 8, 17, 64][ri(0, 5)], 2048 // k)
     d_sae = [1, 7, 260, 4100, 24576][ri(0, 4)]

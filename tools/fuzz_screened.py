@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised comparison of tsc_encode_topk_screened against tsc_encode_topk (finished lists must be bit-identical)
 over shapes the fixed tests do not hit: odd d_sae, several d_in, k 1..64, 1..8 slots, ragged row counts, cold and warm
-lists, duplicated rows (exact ties), scaled inputs.  Usage: fuzz_screened.py [seconds] [seed]"""
+lists, duplicated rows (exact ties), scaled inputs.  Usage: fuzz_screened.py [seconds] [seed] [max cases]"""
 import os
 import sys
 import time
@@ -14,6 +14,7 @@ import tsc_hip  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 60  # stop after this many cases (a deterministic run)
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(seed)
 t0, n_cases, n_calls = time.time(), 0, 0
@@ -23,7 +24,7 @@ def ri(lo, hi):
     return int(torch.randint(lo, hi + 1, (1,), generator=g))
 
 
-while time.time() - t0 < budget:
+while time.time() - t0 < budget and n_cases < max_cases:
     d_in = [128, 256, 384, 768, 1024][ri(0, 4)]
     d_sae = [132, 1536, 4100, 6144, 24576, 24580][ri(0, 5)]
     k = [1, 5, 20, 33, 64][ri(0, 4)]

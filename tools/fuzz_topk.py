@@ -2,7 +2,7 @@
 """Randomised check of tsc_encode_topk (fp32 and bf16 handles) against the exact ranking of the library's OWN dense
 activations (value descending, token id ascending, positives only) on shapes the fixed tests do not hit: every staging
 variant (d_in % 64 == 0: LDS-DMA; other multiples of 4: register staging, k tails), odd d_sae, k 1..64, 1..8 slots,
-ragged row counts over several calls, duplicated rows.  Usage: fuzz_topk.py [seconds] [seed]"""
+ragged row counts over several calls, duplicated rows.  Usage: fuzz_topk.py [seconds] [seed] [max cases]"""
 import os
 import sys
 import time
@@ -15,6 +15,7 @@ import tsc_hip  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 60  # stop after this many cases (a deterministic run)
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(seed)
 t0, n_cases = time.time(), 0
@@ -38,7 +39,7 @@ def rank(acts, k, base):
     return torch.where(live, v, torch.zeros_like(v)), torch.where(live, i + base, torch.full_like(i, -1))
 
 
-while time.time() - t0 < budget:
+while time.time() - t0 < budget and n_cases < max_cases:
     d_in = [4, 8, 28, 36, 100, 128, 192, 256, 768, 772, 1024][ri(0, 10)]
     d_sae = [4, 8, 132, 260, 1536, 4100, 6144, 24576][ri(0, 7)]
     k = [1, 5, 20, 33, 64][ri(0, 4)]
