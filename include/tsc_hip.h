@@ -257,10 +257,39 @@ int tsc_contrib_scores(const tsc_dict_t *dict, const int32_t *feat, const float 
  */
 #define TSC_LENS_COUNT_IS_ZERO 1
 #define TSC_LENS_NO_SCREEN 2
+#define TSC_LENS_EMIT_ONLY 4 /* stop after the emit: feat/val/count hold the unordered emitted pairs (on a screening
+                                handle: the candidates); finish with tsc_sparse_lens_finish_many */
 int tsc_sparse_lens_pass(const tsc_dict_t *dict, const float *x, int64_t M, int max_active, int32_t *feat,
                          float *val, int32_t *count, int flags, const float *dirs,
                          int64_t dir_row_stride, float *recon, float *scores, const float *screen_row_bound,
                          tsc_stream_t stream);
+
+/*
+ * The emits (tsc_sparse_lens_pass with TSC_LENS_EMIT_ONLY) of SEVERAL dictionaries on the same number of rows in one
+ * call: dictionary i reads x[i] [M, d_in] and writes its slice of the stacked feat / val [n_dicts, M, max_active] and
+ * count [n_dicts, M], on streams[i % n_streams] (a 512-row emit is far too short to fill the chip: spread over a few
+ * streams they overlap; the caller orders those streams before and after).  dicts, x, screen_row_bounds (or NULL),
+ * streams: HOST arrays.  flags as tsc_sparse_lens_pass.  At CircuitLens sizes the per-call host time of 24 separate
+ * calls through a foreign-function interface is longer than the kernels; this is one call.
+ */
+int tsc_sparse_lens_emit_many(int n_dicts, const tsc_dict_t *const *dicts, const float *const *x, int64_t M,
+                              int max_active, int32_t *feat, float *val, int32_t *count, int flags,
+                              const float *const *screen_row_bounds, const tsc_stream_t *streams, int n_streams);
+
+/*
+ * The second kernel of tsc_sparse_lens_pass for the rows of SEVERAL dictionaries in one launch (after their emits with
+ * TSC_LENS_EMIT_ONLY, in stream order): at CircuitLens sizes one dictionary's rows are two workgroups per CU, all 24
+ * dictionaries of a pass together fill the chip.  Outputs and emitted pairs are STACKED: feat / val [n_dicts, M,
+ * max_active], count [n_dicts, M], recon [n_dicts, M, d_out] or NULL, scores [n_dicts, M, max_active] or NULL.
+ * dicts, x, dirs: HOST arrays of n_dicts pointers (handles; the inputs each emit saw -- used by screening handles
+ * only; per-dictionary directions [M, d_out] with row stride dir_row_stride, or one shared row with stride 0).
+ * All handles screened or all plain (flags: TSC_LENS_NO_SCREEN as above), same d_in and d_out, n_dicts <= 32.
+ * Results are those of tsc_sparse_lens_pass dictionary by dictionary, bit for bit.
+ */
+int tsc_sparse_lens_finish_many(int n_dicts, const tsc_dict_t *const *dicts, const float *const *x, int64_t M,
+                                int max_active, int32_t *feat, float *val, int32_t *count, int flags,
+                                const float *const *dirs, int64_t dir_row_stride, float *recon, float *scores,
+                                tsc_stream_t stream);
 
 /*
  * The tail of the CircuitLens pass for a batch of rows in ONE launch: per row, assemble the component scores in the

@@ -486,3 +486,49 @@ def test_module_copies_drop_handles_and_autograd_is_refused():
         with pytest.raises(tsc_hip.TscError):
             zs(xr)
         _close(tc.encode(x.to(DEV)), g["tc_encode"])  # inputs that do not require grad are fine with grad mode on
+
+
+@pytest.mark.parametrize("screened", [False, True])
+def test_grouped_finish_equals_the_per_dictionary_lens_pass(screened):
+    """``tsc_sparse_lens_finish_many`` after ``TSC_LENS_EMIT_ONLY`` emits: the same kernel body over the rows of
+    several dictionaries in one launch -- results bit for bit those of ``tsc_sparse_lens_pass`` per dictionary."""
+    import tsc_hip
+    from standins.synthetic_dicts import make_dictionary_weights
+
+    m, cap, n = 77, 512, 3
+    ws = [make_dictionary_weights(768, d_sae, seed=60 + i, b_enc=-1.0) for i, d_sae in enumerate((1536, 1000, 4100))]
+    hs = [_dd(w, compute_dtype=tsc_hip.F32_SCREEN if screened else tsc_hip.F32)[0] for w in ws]
+    gen = torch.Generator().manual_seed(8)
+    xs = [torch.randn(m, 768, generator=gen).to(DEV) for _ in range(n)]
+    dirs = [torch.randn(m, 768, generator=gen).to(DEV) for _ in range(n)]
+    ref = [h.sparse_lens_pass(x, cap, dirs=d) for h, x, d in zip(hs, xs, dirs)]
+    feat = torch.empty(n, m, cap, dtype=torch.int32, device=DEV)
+    val = torch.empty(n, m, cap, device=DEV)
+    count = torch.zeros(n, m, dtype=torch.int32, device=DEV)
+    recon = torch.empty(n, m, 768, device=DEV)
+    scores = torch.empty(n, m, cap, device=DEV)
+    for i, (h, x, d) in enumerate(zip(hs, xs, dirs)):
+        h.sparse_lens_pass(x, cap, dirs=d, emit_only=True,
+                           out={"feat": feat[i], "val": val[i], "count": count[i], "recon": recon[i], "scores": scores[i]})
+    tsc_hip.sparse_lens_finish_many(hs, xs, feat, val, count, dirs=dirs, recon=recon, scores=scores)
+    for i, (f, v, c, r, s) in enumerate(ref):
+        assert int(c.max()) <= cap and int(c.sum()) > 5 * m
+        assert torch.equal(count[i], c) and torch.equal(feat[i], f) and torch.equal(val[i], v)
+        assert torch.equal(recon[i], r) and torch.equal(scores[i], s)
+    # without scores / reconstruction, the emits through the one-call form (two streams), and the argument checks
+    count.zero_()
+    side = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for st in side:
+        st.wait_stream(torch.cuda.current_stream())
+    tsc_hip.sparse_lens_emit_many(hs, xs, feat, val, count, streams=side,
+                                  row_bounds=torch.stack([tsc_hip.screen_row_bound(x, w["b_dec"].to(DEV)) for x, w in zip(xs, ws)]) if screened else None)
+    for st in side:
+        torch.cuda.current_stream().wait_stream(st)
+    tsc_hip.sparse_lens_finish_many(hs, xs, feat, val, count)
+    assert all(torch.equal(feat[i], ref[i][0]) and torch.equal(val[i], ref[i][1]) for i in range(n))
+    with pytest.raises(tsc_hip.TscError):
+        tsc_hip.sparse_lens_finish_many(hs[:2], xs[:2], feat, val, count)
+    if screened:
+        mixed = [hs[0], _dd(ws[1])[0], hs[2]]
+        with pytest.raises(tsc_hip.TscError):
+            tsc_hip.sparse_lens_finish_many(mixed, xs, feat, val, count)

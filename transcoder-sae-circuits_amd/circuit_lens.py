@@ -285,6 +285,18 @@ class _PromptCacheView:
 _PASS_STREAMS: Dict[str, list] = {}
 
 
+_TRACE = [] if os.environ.get("TSC_LENS_TRACE") else None  # profiling aid: (label, event on the current stream, host time)
+
+
+def _mark(label: str) -> None:
+    if _TRACE is not None:
+        import time
+
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        _TRACE.append((label, ev, time.perf_counter()))
+
+
 def _pass_streams(dev, n: int = 4):
     key = str(dev)
     if key not in _PASS_STREAMS:
@@ -331,9 +343,20 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
         main = torch.cuda.current_stream(dev)
         n_side = int(os.environ.get("TSC_LENS_STREAMS", "4"))  # 1: everything on the current stream (profiling)
         side = _pass_streams(dev, n_side) if rows <= 8192 and n_d > 1 and n_side > 1 else []
+        # ... and, with several dictionaries, stop each after its emit and finish them all in ONE launch
+        # (tsc_sparse_lens_finish_many): one dictionary's 512 rows are two workgroups per CU, 24 x 512 fill the chip.
+        grouped = 1 < n_d <= 32 and rows <= 8192 and len({h.compute_dtype for h in handles}) == 1 and \
+            os.environ.get("TSC_LENS_GROUPED", "1") != "0"
+        _mark("pass: buffers ready")
         start = torch.cuda.Event()
         start.record(main)
-        for i, (h, x) in enumerate(zip(handles, inputs)):
+        if grouped:  # every emit in one foreign call (24 separate calls cost more host time than their kernels run)
+            for stream in side:
+                stream.wait_event(start)
+            tsc_hip.sparse_lens_emit_many(handles, inputs, feat, val, count, screen=screened,
+                                          row_bounds=row_bounds if screened and handles[0].compute_dtype == tsc_hip.F32_SCREEN else None,
+                                          streams=side or None)
+        for i, (h, x) in enumerate(zip(handles, inputs) if not grouped else ()):
             stream = side[i % len(side)] if side else main
             if side and i < len(side):
                 stream.wait_event(start)
@@ -342,14 +365,22 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
                                    row_bound=row_bounds[i:i + 1] if screened and h.compute_dtype == tsc_hip.F32_SCREEN else None,
                                    out={"feat": feat[i], "val": val[i], "count": count[i],
                                         "recon": recon[i] if want_recon else None,
-                                        "scores": scores[i] if scores is not None else None})
+                                        "scores": scores[i] if scores is not None else None},
+                                   want_recon=want_recon, emit_only=grouped)
         for stream in side:
             main.wait_stream(stream)
+        _mark("pass: emits done")
+        if grouped:
+            tsc_hip.sparse_lens_finish_many(handles, inputs, feat, val, count, dirs=dirs, recon=recon, scores=scores,
+                                            screen=screened)
         # work that only consumes this pass's device buffers is queued BEFORE the host looks at the counts, so the
         # GPU never drains in the middle of the pass; it is redone in the (rare) retry with a larger capacity
+        _mark("pass: finish done")
         if then is not None:
             tail = then(feat, val, count, recon, scores)
+        _mark("pass: tail queued")
         counts_host = count.cpu()  # the one synchronisation of the pass
+        _mark("pass: counts on host")
         worst = int(counts_host.max()) if counts_host.numel() else 0
         if worst <= cap:
             if then is not None:
@@ -862,11 +893,13 @@ class BatchedCircuitLens:
         dictionaries before the host reads the counts; ties rank by column (the reference's ``topk`` leaves them open)."""
         import tsc_hip
 
+        _mark("lens: start")
         d = self._row_directions(directions)
         encs, xs = self._encoders_and_inputs()
         with torch.no_grad():
             dirs, dz = self._dictionary_directions(d)
             t = self._tables()
+            _mark("lens: directions ready")
             n_layers, rows = self.model.cfg.n_layers, self.n_rows
 
             def tail(feat, val, count, recon, scores):
@@ -886,6 +919,7 @@ class BatchedCircuitLens:
                 encs, xs, self.max_active, dirs=dirs, screened=self.screened, row_bounds=self._row_bounds(), then=tail)
             if self._pass is None:
                 self._pass = (feat, val, count, recon, scores, counts_host)
+            _mark("lens: pass returned")
             info = res["top_info"].long()  # [R, k, 4]: column, component, layer, feature (-1 where a row ran out)
             out = {
                 "top_values": res["top_values"],

@@ -354,14 +354,57 @@ int tsc_sparse_lens_pass(const tsc_dict_t *d, const float *x, int64_t M, int max
         a.screen_wnorm = d->wnorm;
         a.screen_bound = screen_row_bound;
         rc = tsc_launch_encode_bf16(TSC_MODE_SPARSE, a, d->W_enc_bf16, d->x_bf16, s);
-        if (rc) return rc;
+        if (rc || (flags & TSC_LENS_EMIT_ONLY)) return rc;
         return tsc_launch_sparse_finish(d->W_dec, d->out_bias, d->d_out, feat, val, count, M, max_active, dirs,
                                         dir_row_stride, recon, scores, x, d->W_enc_t, d->bias_fold, d->d_in, s);
     }
     rc = run_encode(d, TSC_MODE_SPARSE, a, s);
-    if (rc) return rc;
+    if (rc || (flags & TSC_LENS_EMIT_ONLY)) return rc;
     return tsc_launch_sparse_finish(d->W_dec, d->out_bias, d->d_out, feat, val, count, M, max_active, dirs,
                                     dir_row_stride, recon, scores, nullptr, nullptr, nullptr, 0, s);
+}
+
+int tsc_sparse_lens_emit_many(int n_dicts, const tsc_dict_t *const *dicts, const float *const *x, int64_t M,
+                              int max_active, int32_t *feat, float *val, int32_t *count, int flags,
+                              const float *const *screen_row_bounds, const tsc_stream_t *streams, int n_streams) {
+    if (n_dicts < 0 || M < 0) return tsc_fail(TSC_ERR_ARG, "negative count");
+    if (n_dicts == 0 || M == 0) return TSC_OK;
+    if (!dicts || !x || !feat || !val || !count) return tsc_fail(TSC_ERR_ARG, "null lens_emit_many pointer");
+    if (n_streams < 1 || !streams) return tsc_fail(TSC_ERR_ARG, "lens_emit_many needs at least one stream");
+    for (int i = 0; i < n_dicts; ++i) {
+        const int rc = tsc_sparse_lens_pass(dicts[i], x[i], M, max_active, feat + (size_t)i * M * max_active,
+                                            val + (size_t)i * M * max_active, count + (size_t)i * M,
+                                            flags | TSC_LENS_EMIT_ONLY, nullptr, 0, nullptr, nullptr,
+                                            screen_row_bounds ? screen_row_bounds[i] : nullptr, streams[i % n_streams]);
+        if (rc) return rc;
+    }
+    return TSC_OK;
+}
+
+int tsc_sparse_lens_finish_many(int n_dicts, const tsc_dict_t *const *dicts, const float *const *x, int64_t M,
+                                int max_active, int32_t *feat, float *val, int32_t *count, int flags,
+                                const float *const *dirs, int64_t dir_row_stride, float *recon, float *scores,
+                                tsc_stream_t stream) {
+    if (n_dicts < 0 || M < 0) return tsc_fail(TSC_ERR_ARG, "negative count");
+    if (n_dicts == 0 || M == 0) return TSC_OK;
+    if (!dicts || !feat || !val || !count) return tsc_fail(TSC_ERR_ARG, "null lens_finish_many pointer");
+    if (max_active < 1) return tsc_fail(TSC_ERR_ARG, "max_active %d < 1", max_active);
+    if (recon && !aligned16(recon)) return tsc_fail(TSC_ERR_ARG, "recon must be 16-byte aligned");
+    int screened = -1;
+    for (int i = 0; i < n_dicts; ++i) {
+        if (!dicts[i]) return tsc_fail(TSC_ERR_ARG, "null dictionary handle %d", i);
+        const int sc = dicts[i]->compute_dtype == TSC_F32_SCREEN && dicts[i]->W_enc_t && !(flags & TSC_LENS_NO_SCREEN);
+        if (screened >= 0 && sc != screened)
+            return tsc_fail(TSC_ERR_ARG, "grouped finish: the dictionaries must all be screened or all plain");
+        screened = sc;
+        if (sc && (!x || !x[i] || !aligned16(x[i]))) return tsc_fail(TSC_ERR_ARG, "screened finish needs the 16-byte aligned inputs x[%d]", i);
+        if (scores && (!dirs || !dirs[i] || !aligned16(dirs[i])))
+            return tsc_fail(TSC_ERR_ARG, "scores need 16-byte aligned directions (dictionary %d)", i);
+    }
+    if (scores && dir_row_stride != 0 && (dir_row_stride < dicts[0]->d_out || (dir_row_stride & 3)))
+        return tsc_fail(TSC_ERR_ARG, "direction row stride must be 0 or >= d_out and a multiple of 4");
+    return tsc_launch_sparse_finish_many(n_dicts, dicts, x, M, max_active, feat, val, count, dirs, dir_row_stride,
+                                         recon, scores, screened, (hipStream_t)stream);
 }
 
 int tsc_lens_assemble(int64_t R, int n_head, int n_groups, const int32_t *group_aux, int max_active, const float *head,

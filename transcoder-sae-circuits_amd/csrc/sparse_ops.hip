@@ -8,6 +8,8 @@
 //   decode_sparse  : recon[m] = bias + sum_i val * W_dec[feat]  (mlp_transcoder.py:128-147, z_sae.py:62)
 //   contrib        : scores[m,i,d] = val * dot(W_dec[feat], dirs[d])  (circuit_lens.py:762-766,
 //                    955-957, 1151-1164 restricted to active features)
+#include <cstring>
+
 #include "tsc_internal.h"
 
 namespace {
@@ -230,31 +232,30 @@ constexpr int FIN_CPL = 12;           // float4 chunks of a W_dec row per lane o
 // dot(x[m], W_enc^T[f]) + bias'[f], a quarter wave per candidate over the contiguous row of the transposed copy --
 // and keeps the positive ones; count[m] becomes the true number of active features (unless the candidates
 // overflowed the capacity: then it is left above max_active so that the caller retries).
+// One row (= one workgroup of 256 threads).  frow / vrow / count_m: the row's emitted pairs and their number; dir_row,
+// recon_row, score_row: the row's direction and outputs (score_row == nullptr: no scores; recon_row == nullptr: no
+// reconstruction); x_row, W_enc_t, bias_fold, d_in: the exact recompute of a screened emit.
 template <bool SCREENED>
-__global__ __launch_bounds__(256) void sparse_finish_kernel(const float *W_dec, const float *bias, int d_out, int *feat,
-                                                           float *val, int *count, int max_active,
-                                                           const float *dirs, long long dir_stride, float *recon,
-                                                           float *scores, const float *x, const float *W_enc_t,
-                                                           const float *bias_fold, int d_in) {
+__device__ __forceinline__ void finish_row(const float *W_dec, const float *bias, int d_out, int *frow, float *vrow,
+                                           int *count_m, int max_active, const float *dir_row, float *recon_row,
+                                           float *score_row, const float *x_row, const float *W_enc_t,
+                                           const float *bias_fold, int d_in) {
     __shared__ float sv[FIN_MAX_ACTIVE];
     __shared__ int sf[FIN_MAX_ACTIVE];
     __shared__ f32x4 sd[FIN_CPL * 16];        // the token's direction
     __shared__ f32x4 red[4][FIN_CPL * 16];    // per-wave partial reconstructions
     __shared__ int n_live;
-    const long long m = blockIdx.x;
     const int tid = threadIdx.x;
-    const int c_emitted = count[m];
+    const int c_emitted = *count_m;
     int c = c_emitted;
     if (c > max_active) c = max_active;
-    int *frow = feat + m * max_active;
-    float *vrow = val + m * max_active;
     const int chunks = d_out >> 2;
     for (int e = tid; e < c; e += 256) {
         sv[e] = vrow[e];
         sf[e] = frow[e];
     }
-    if (scores)
-        for (int i = tid; i < chunks; i += 256) sd[i] = ((const f32x4 *)(dirs + m * dir_stride))[i];
+    if (score_row)
+        for (int i = tid; i < chunks; i += 256) sd[i] = ((const f32x4 *)dir_row)[i];
     if (SCREENED && tid == 0) n_live = 0;
     __syncthreads();
     if constexpr (SCREENED) {
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void sparse_finish_kernel(const float *W_dec, 
 #pragma unroll
         for (int j = 0; j < FIN_CPL; ++j) {
             const int ch = l16 + 16 * j;
-            xr[j] = ch < kchunks ? ((const f32x4 *)(x + m * d_in))[ch] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            xr[j] = ch < kchunks ? ((const f32x4 *)x_row)[ch] : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         for (int e = grp; e < c; e += 16) {
             const int f = sf[e];
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256) void sparse_finish_kernel(const float *W_dec, 
     __syncthreads();
     if constexpr (SCREENED) {
         c = n_live;
-        if (tid == 0 && c_emitted <= max_active) count[m] = c;
+        if (tid == 0 && c_emitted <= max_active) *count_m = c;
     }
 #pragma unroll
     for (int j = 0; j < EPT; ++j)
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void sparse_finish_kernel(const float *W_dec, 
             const int ch = l16 + 16 * j;
             w[j] = ch < chunks ? src[ch] : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        if (scores) {
+        if (score_row) {
             float part = 0.f;
 #pragma unroll
             for (int j = 0; j < FIN_CPL; ++j) {
@@ -349,14 +350,14 @@ __global__ __launch_bounds__(256) void sparse_finish_kernel(const float *W_dec, 
             }
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off);
-            if (l16 == 0) scores[m * max_active + e] = part * v;
+            if (l16 == 0) score_row[e] = part * v;
         }
 #pragma unroll
         for (int j = 0; j < FIN_CPL; ++j) acc[j] += w[j] * v;
     }
-    if (scores)
-        for (int e = c + tid; e < max_active; e += 256) scores[m * max_active + e] = 0.f;
-    if (recon) {
+    if (score_row)
+        for (int e = c + tid; e < max_active; e += 256) score_row[e] = 0.f;
+    if (recon_row) {
         // quarter waves of one wave -> lanes 0..15; waves -> LDS; fixed order, so the result is reproducible
 #pragma unroll
         for (int j = 0; j < FIN_CPL; ++j) {
@@ -375,9 +376,46 @@ __global__ __launch_bounds__(256) void sparse_finish_kernel(const float *W_dec, 
         __syncthreads();
         for (int ch = tid; ch < chunks; ch += 256) {
             f32x4 b = bias ? ((const f32x4 *)bias)[ch] : (f32x4){0.f, 0.f, 0.f, 0.f};
-            ((f32x4 *)(recon + m * d_out))[ch] = ((red[0][ch] + red[1][ch]) + (red[2][ch] + red[3][ch])) + b;
+            ((f32x4 *)recon_row)[ch] = ((red[0][ch] + red[1][ch]) + (red[2][ch] + red[3][ch])) + b;
         }
     }
+}
+
+template <bool SCREENED>
+__global__ __launch_bounds__(256) void sparse_finish_kernel(const float *W_dec, const float *bias, int d_out, int *feat,
+                                                           float *val, int *count, int max_active,
+                                                           const float *dirs, long long dir_stride, float *recon,
+                                                           float *scores, const float *x, const float *W_enc_t,
+                                                           const float *bias_fold, int d_in) {
+    const long long m = blockIdx.x;
+    finish_row<SCREENED>(W_dec, bias, d_out, feat + m * max_active, val + m * max_active, count + m, max_active,
+                         scores ? dirs + m * dir_stride : nullptr, recon ? recon + m * d_out : nullptr,
+                         scores ? scores + m * max_active : nullptr, SCREENED ? x + m * d_in : nullptr, W_enc_t, bias_fold,
+                         d_in);
+}
+
+// The same for the rows of SEVERAL dictionaries in one launch (grid = n_dicts * M): at CircuitLens sizes one
+// dictionary's 512 rows are two workgroups per CU; all dictionaries of a pass together keep every CU full.  Outputs
+// are stacked [n_dicts, M, ...]; what differs per dictionary travels in the kernel arguments.
+constexpr int FIN_MANY_MAX = 32;
+struct FinishManyArgs {
+    struct One {
+        const float *W_dec, *bias, *dirs, *x, *W_enc_t, *bias_fold;
+    } d[FIN_MANY_MAX];
+    long long M, dir_stride;
+    int d_out, d_in, max_active;
+    int *feat, *count;
+    float *val, *recon, *scores;
+};
+template <bool SCREENED>
+__global__ __launch_bounds__(256) void sparse_finish_many_kernel(const FinishManyArgs p) {
+    const int di = (int)(blockIdx.x / p.M);  // uniform: the dictionary's pointers are scalar loads
+    const long long m = blockIdx.x - di * p.M, r = di * p.M + m;
+    const FinishManyArgs::One &o = p.d[di];
+    finish_row<SCREENED>(o.W_dec, o.bias, p.d_out, p.feat + r * p.max_active, p.val + r * p.max_active, p.count + r,
+                         p.max_active, p.scores ? o.dirs + m * p.dir_stride : nullptr,
+                         p.recon ? p.recon + r * p.d_out : nullptr, p.scores ? p.scores + r * p.max_active : nullptr,
+                         SCREENED ? o.x + m * p.d_in : nullptr, o.W_enc_t, o.bias_fold, p.d_in);
 }
 
 // The tail of the CircuitLens pass for a batch of rows, ONE launch: assemble each row's component scores in the
@@ -736,6 +774,36 @@ int tsc_launch_sparse_finish(const float *W_dec, const float *bias, int d_out, i
         hipLaunchKernelGGL(sparse_finish_kernel<false>, dim3((unsigned)M), dim3(256), 0, stream, W_dec, bias, d_out, feat,
                            val, count, max_active, dirs, dir_stride, recon, scores, x, W_enc_t, bias_fold, d_in);
     }
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
+int tsc_launch_sparse_finish_many(int n, const tsc_dict *const *dicts, const float *const *x, long long M,
+                                  int max_active, int *feat, float *val, int *count, const float *const *dirs,
+                                  long long dir_stride, float *recon, float *scores, int screened, hipStream_t stream) {
+    if (M <= 0 || n <= 0) return TSC_OK;
+    if (n > FIN_MANY_MAX) return tsc_fail(TSC_ERR_UNSUPPORTED, "at most %d dictionaries per grouped finish (got %d)", FIN_MANY_MAX, n);
+    if ((long long)n * M > 0x7fffffffLL) return tsc_fail(TSC_ERR_UNSUPPORTED, "grouped finish grid out of range");
+    FinishManyArgs p;
+    memset(&p, 0, sizeof(p));
+    const int d_out = dicts[0]->d_out, d_in = dicts[0]->d_in;
+    if (!tsc_sparse_finish_supported(d_out, max_active))
+        return tsc_fail(TSC_ERR_UNSUPPORTED, "fused lens pass needs d_out <= %d and max_active <= %d (got %d, %d)",
+                        FIN_CPL * 64, FIN_MAX_ACTIVE, d_out, max_active);
+    for (int i = 0; i < n; ++i) {
+        const tsc_dict *d = dicts[i];
+        if (d->d_out != d_out || d->d_in != d_in) return tsc_fail(TSC_ERR_ARG, "grouped finish: dictionary %d has other d_in / d_out", i);
+        if (!d->W_dec) return tsc_fail(TSC_ERR_ARG, "dictionary %d was created without W_dec", i);
+        if (screened && (!d->W_enc_t || !d->bias_fold || !x || !x[i] || d_in > FIN_CPL * 64 || (d_in & 3)))
+            return tsc_fail(TSC_ERR_UNSUPPORTED, "grouped screened finish needs TSC_F32_SCREEN handles, their inputs and d_in <= %d", FIN_CPL * 64);
+        p.d[i].W_dec = d->W_dec; p.d[i].bias = d->out_bias; p.d[i].dirs = dirs ? dirs[i] : nullptr;
+        p.d[i].x = screened ? x[i] : nullptr; p.d[i].W_enc_t = d->W_enc_t; p.d[i].bias_fold = d->bias_fold;
+    }
+    p.M = M; p.dir_stride = dir_stride; p.d_out = d_out; p.d_in = d_in; p.max_active = max_active;
+    p.feat = feat; p.count = count; p.val = val; p.recon = recon; p.scores = scores;
+    const dim3 grid((unsigned)(n * M)), block(256);
+    if (screened) hipLaunchKernelGGL(sparse_finish_many_kernel<true>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(sparse_finish_many_kernel<false>, grid, block, 0, stream, p);
     TSC_HIP_CHECK(hipGetLastError());
     return TSC_OK;
 }

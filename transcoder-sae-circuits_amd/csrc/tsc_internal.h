@@ -98,6 +98,9 @@ int tsc_launch_contrib(const float *W_dec, int d_out, const int *feat, const flo
                        const int *count, long long M, int max_active, const float *dirs, int n_dir,
                        float *scores, hipStream_t stream);
 int tsc_sparse_finish_supported(int d_out, int max_active);
+int tsc_launch_sparse_finish_many(int n, const tsc_dict *const *dicts, const float *const *x, long long M,
+                                  int max_active, int *feat, float *val, int *count, const float *const *dirs,
+                                  long long dir_stride, float *recon, float *scores, int screened, hipStream_t stream);
 int tsc_launch_lens_assemble(long long R, int n_head, int n_groups, const int *group_aux, int cap, const float *head,
                              const float *aux, const float *scores, const int *count, const int *tags, const int *feat,
                              int k, float *raw, float *acts, unsigned char *mask, float *top_v, int *top_info,

@@ -55,6 +55,11 @@ _SIGNATURES = {
     "tsc_sparse_lens_pass": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p,
                                         _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p,
                                         _c.c_void_p, _c.c_void_p]),
+    "tsc_sparse_lens_emit_many": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p,
+                                             _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int]),
+    "tsc_sparse_lens_finish_many": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p,
+                                               _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_void_p,
+                                               _c.c_void_p, _c.c_void_p]),
     "tsc_lens_assemble": (_c.c_int, [_c.c_int64, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
                                      _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
                                      _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
@@ -250,7 +255,7 @@ class DeviceDict:
 
     def sparse_lens_pass(self, x: torch.Tensor, max_active: int = 512, dirs: Optional[torch.Tensor] = None,
                          want_recon: bool = True, out: Optional[dict] = None, row_bound: Optional[torch.Tensor] = None,
-                         screen: bool = True):
+                         screen: bool = True, emit_only: bool = False):
         """``tsc_sparse_lens_pass``: sparse emit + (sort, reconstruction, per-row direction scores) in two launches.
 
         ``dirs``: ``[M, d_out]`` (one direction per row), ``[d_out]`` (shared) or None.  Returns ``(feat, val, count,
@@ -259,7 +264,8 @@ class DeviceDict:
         preallocated ``feat/val/count`` (and optionally ``recon/scores``) views -- ``count`` then has to be zero
         already -- so that one memset and one reduction serve a whole pass).  ``row_bound``: one-element device
         tensor for a ``F32_SCREEN`` handle (see :func:`screen_row_bound`); None lets the library compute it;
-        ``screen=False`` asks such a handle for the plain fp32 emit."""
+        ``screen=False`` asks such a handle for the plain fp32 emit.  ``emit_only``: stop after the emit
+        (``TSC_LENS_EMIT_ONLY``); :func:`sparse_lens_finish_many` then finishes several dictionaries in one launch."""
         x2 = _dev(x, torch.float32, "x").reshape(-1, self.d_in)
         m = x2.shape[0]
         cap = max(1, min(int(max_active), LENS_PASS_MAX_ACTIVE, self.d_sae))
@@ -290,7 +296,7 @@ class DeviceDict:
             dptr = dirs.data_ptr()
         with torch.cuda.device(dev):
             _check(lib().tsc_sparse_lens_pass(self._handle, x2.data_ptr(), m, cap, feat.data_ptr(), val.data_ptr(),
-                                              count.data_ptr(), zeroed | (0 if screen else 2), dptr, stride,
+                                              count.data_ptr(), zeroed | (0 if screen else 2) | (4 if emit_only else 0), dptr, stride,
                                               recon.data_ptr() if recon is not None else None,
                                               scores.data_ptr() if scores is not None else None,
                                               _dev(row_bound, torch.float32, "row_bound").data_ptr() if row_bound is not None else None,
@@ -327,6 +333,64 @@ class DeviceDict:
             _check(lib().tsc_contrib_scores(self._handle, feat.data_ptr(), val.data_ptr(), count.data_ptr(), m, cap,
                                             dirs.data_ptr(), dirs.shape[0], out.data_ptr(), _stream()))
         return out
+
+
+def sparse_lens_emit_many(handles, inputs, feat: torch.Tensor, val: torch.Tensor, count: torch.Tensor,
+                          screen: bool = True, row_bounds: Optional[torch.Tensor] = None, streams=None,
+                          count_is_zero: bool = True) -> None:
+    """``tsc_sparse_lens_emit_many``: the emits of all ``handles`` into the stacked ``feat / val [D, M, cap]`` and
+    ``count [D, M]`` in ONE foreign call, dictionary ``i`` on ``streams[i % len(streams)]`` (``torch.cuda.Stream``s;
+    default: the current one).  ``row_bounds [D]``: the screens' row bounds (device), or None."""
+    n = len(handles)
+    _dev(feat, torch.int32, "feat"); _dev(val, torch.float32, "val"); _dev(count, torch.int32, "count")
+    D, M, cap = feat.shape
+    if D != n or tuple(count.shape) != (n, M) or tuple(val.shape) != (n, M, cap):
+        raise TscError("sparse_lens_emit_many: stacked buffers do not match the number of dictionaries")
+    hs = (ctypes.c_void_p * n)(*[h._handle for h in handles])
+    xs = (ctypes.c_void_p * n)(*[_dev(x, torch.float32, "x").data_ptr() for x in inputs])
+    for x, h in zip(inputs, handles):
+        if x.dim() != 2 or x.shape[0] != M or x.shape[1] != h.d_in:
+            raise TscError(f"sparse_lens_emit_many: every input must be [{M}, d_in] (got {tuple(x.shape)})")
+    rb = None
+    if row_bounds is not None:
+        row_bounds = _dev(row_bounds, torch.float32, "row_bounds")
+        if row_bounds.numel() != n:
+            raise TscError("sparse_lens_emit_many: one row bound per dictionary")
+        rb = (ctypes.c_void_p * n)(*[row_bounds.data_ptr() + 4 * i for i in range(n)])
+    st = [s.cuda_stream for s in streams] if streams else [_stream()]
+    sa = (ctypes.c_void_p * len(st))(*st)
+    with torch.cuda.device(feat.device):
+        _check(lib().tsc_sparse_lens_emit_many(n, hs, xs, M, cap, feat.data_ptr(), val.data_ptr(), count.data_ptr(),
+                                               (1 if count_is_zero else 0) | (0 if screen else 2), rb, sa, len(st)))
+
+
+def sparse_lens_finish_many(handles, inputs, feat: torch.Tensor, val: torch.Tensor, count: torch.Tensor, dirs=None,
+                            recon: Optional[torch.Tensor] = None, scores: Optional[torch.Tensor] = None,
+                            screen: bool = True) -> None:
+    """``tsc_sparse_lens_finish_many``: the second kernel of the lens pass for all ``handles`` (``DeviceDict``s, up to
+    32) in one launch, after their ``sparse_lens_pass(..., emit_only=True)`` calls into the stacked buffers
+    ``feat / val [D, M, cap]``, ``count [D, M]`` (in stream order).  ``inputs``: the ``[M, d_in]`` tensors the emits
+    saw; ``dirs``: per-dictionary ``[M, d_out]`` tensors (or None); ``recon [D, M, d_out]`` / ``scores [D, M, cap]``."""
+    n = len(handles)
+    _dev(feat, torch.int32, "feat"); _dev(val, torch.float32, "val"); _dev(count, torch.int32, "count")
+    D, M, cap = feat.shape
+    if D != n or tuple(count.shape) != (n, M) or tuple(val.shape) != (n, M, cap):
+        raise TscError("sparse_lens_finish_many: stacked buffers do not match the number of dictionaries")
+    hs = (ctypes.c_void_p * n)(*[h._handle for h in handles])
+    xs = (ctypes.c_void_p * n)(*[_dev(x, torch.float32, "x").data_ptr() for x in inputs])
+    ds = None
+    if scores is not None:
+        if dirs is None:
+            raise TscError("scores need directions")
+        ds = (ctypes.c_void_p * n)(*[_dev(d, torch.float32, "dirs").data_ptr() for d in dirs])
+        _dev(scores, torch.float32, "scores")
+    if recon is not None:
+        _dev(recon, torch.float32, "recon")
+    with torch.cuda.device(feat.device):
+        _check(lib().tsc_sparse_lens_finish_many(n, hs, xs, M, cap, feat.data_ptr(), val.data_ptr(), count.data_ptr(),
+                                                 0 if screen else 2, ds, handles[0].d_out,
+                                                 recon.data_ptr() if recon is not None else None,
+                                                 scores.data_ptr() if scores is not None else None, _stream()))
 
 
 def screen_row_bound(x: torch.Tensor, b_dec: torch.Tensor) -> torch.Tensor:
