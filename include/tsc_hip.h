@@ -267,10 +267,12 @@ int tsc_sparse_lens_pass(const tsc_dict_t *dict, const float *x, int64_t M, int 
 /*
  * The emits (tsc_sparse_lens_pass with TSC_LENS_EMIT_ONLY) of SEVERAL dictionaries on the same number of rows in one
  * call: dictionary i reads x[i] [M, d_in] and writes its slice of the stacked feat / val [n_dicts, M, max_active] and
- * count [n_dicts, M], on streams[i % n_streams] (a 512-row emit is far too short to fill the chip: spread over a few
- * streams they overlap; the caller orders those streams before and after).  dicts, x, screen_row_bounds (or NULL),
- * streams: HOST arrays.  flags as tsc_sparse_lens_pass.  At CircuitLens sizes the per-call host time of 24 separate
- * calls through a foreign-function interface is longer than the kernels; this is one call.
+ * count [n_dicts, M].  Screening handles of one input width (the CircuitLens case) run as ONE grouped launch on
+ * streams[0]: a 512-row emit is 1.5 rounds of single-tile workgroups, and emits on different streams do not pack into
+ * each other's idle half round -- one grid over all dictionaries does.  Otherwise dictionary i runs on
+ * streams[i % n_streams].  Either way the caller orders ALL the streams before and after.  dicts, x,
+ * screen_row_bounds (or NULL), streams: HOST arrays.  flags as tsc_sparse_lens_pass.  Results are those of the
+ * separate calls (the order in which a row's pairs are emitted is unspecified either way).
  */
 int tsc_sparse_lens_emit_many(int n_dicts, const tsc_dict_t *const *dicts, const float *const *x, int64_t M,
                               int max_active, int32_t *feat, float *val, int32_t *count, int flags,

@@ -371,6 +371,37 @@ int tsc_sparse_lens_emit_many(int n_dicts, const tsc_dict_t *const *dicts, const
     if (n_dicts == 0 || M == 0) return TSC_OK;
     if (!dicts || !x || !feat || !val || !count) return tsc_fail(TSC_ERR_ARG, "null lens_emit_many pointer");
     if (n_streams < 1 || !streams) return tsc_fail(TSC_ERR_ARG, "lens_emit_many needs at least one stream");
+    // Screening handles of one input width: ONE grouped launch on streams[0] (a 512-row emit is 1.5 rounds of
+    // single-tile workgroups; emits on different streams do not pack into each other's idle half round, one grid does)
+    bool group = n_dicts > 1 && n_dicts <= 32 && M <= 32768 && !(flags & TSC_LENS_NO_SCREEN);
+    for (int i = 0; i < n_dicts && group; ++i)
+        group = dicts[i] && dicts[i]->compute_dtype == TSC_F32_SCREEN && dicts[i]->W_enc_t && dicts[i]->W_enc_bf16 &&
+                dicts[i]->d_in == dicts[0]->d_in && x[i] && aligned16(x[i]);
+    if (group) {
+        if (max_active < 1 || !tsc_sparse_finish_supported(dicts[0]->d_out, max_active))
+            return tsc_fail(TSC_ERR_UNSUPPORTED, "tsc_sparse_lens_emit_many needs d_out <= 768 and 1 <= max_active <= 2048");
+        hipStream_t s = (hipStream_t)streams[0];
+        if (!(flags & TSC_LENS_COUNT_IS_ZERO)) TSC_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)n_dicts * M * sizeof(int32_t), s));
+        EmitGroupProblem p[32];
+        const float *b_decs[32];
+        void *stagings[32];
+        for (int i = 0; i < n_dicts; ++i) { b_decs[i] = dicts[i]->b_dec; stagings[i] = dicts[i]->x_bf16; }
+        int rc = tsc_launch_convert_x_bf16_group(n_dicts, x, b_decs, stagings, M, dicts[0]->d_in, s);
+        if (rc) return rc;
+        for (int i = 0; i < n_dicts; ++i) {
+            const tsc_dict_t *d = dicts[i];
+            const float *bound = screen_row_bounds ? screen_row_bounds[i] : nullptr;
+            if (!bound) {
+                rc = tsc_launch_row_bound(x[i], M, d->d_in, d->b_dec, d->screen_bound, s);
+                if (rc) return rc;
+                bound = d->screen_bound;
+            }
+            p[i].x_bf16 = d->x_bf16; p[i].W_bf16 = d->W_enc_bf16; p[i].b_enc = d->b_enc; p[i].wnorm = d->wnorm;
+            p[i].bound = bound; p[i].feat = feat + (size_t)i * M * max_active; p[i].val = val + (size_t)i * M * max_active;
+            p[i].count = count + (size_t)i * M; p[i].N = d->d_sae;
+        }
+        return tsc_launch_emit_group(n_dicts, p, M, dicts[0]->d_in, max_active, s);
+    }
     for (int i = 0; i < n_dicts; ++i) {
         const int rc = tsc_sparse_lens_pass(dicts[i], x[i], M, max_active, feat + (size_t)i * M * max_active,
                                             val + (size_t)i * M * max_active, count + (size_t)i * M,

@@ -29,6 +29,7 @@
 // the matrix pipe about as much as it would cost the VALU, so the design rule throughout is: as few
 // non-MFMA instructions per MFMA as possible.
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <type_traits>
 
@@ -119,8 +120,10 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // BF16 (needs DMA; K % 128 == 0): a.x is bf16(x - b_dec) [M][K] and a.W is bf16(W_enc) transposed [N][K],
 // both prepared by encode_bf16.hip; a k-step is 64 k (the same 128-byte rows), the W tile is staged exactly
 // like the x tile, and one v_mfma_f32_32x32x16_bf16 replaces four fp32 MFMAs.
+// (the body is a device function so that the grouped launch below can run it for several dictionaries; `wg` is the
+// workgroup's index within ITS problem's grid)
 template <class C, int MODE, bool KALIGNED, bool DMA, bool LLDS, bool BF16>
-__global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeArgs a) {
+__device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
     constexpr int WMB = C::WMB, WNB = C::WNB, BM = C::BM, BN = C::BN;
     constexpr int LDA_ = DMA ? BK : LDA;
     constexpr int ES = BF16 ? 2 : 4;  // bytes per staged element; a k-step is 128 bytes of every row
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
     // token tiles they stream are shared.  A speed heuristic only.
     int nt, slot;
     {
-        const int w = blockIdx.x;
+        const int w = wg;
         if ((a.n_tiles_n & 7) == 0) {
             const int q = w >> 3;
             nt = (w & 7) + 8 * (q / a.m_split);
@@ -425,8 +428,8 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
             ++ep_tiles;
             auto direct = [&](long long row, int col, float v) {
                 if (a.sq_entries) {  // top-k screen: the workgroup's own candidate queue
-                    const int pos = atomicAdd(a.sq_counters + blockIdx.x, 1);
-                    if (pos < a.sq_cap) a.sq_entries[(size_t)blockIdx.x * a.sq_cap + pos] = ((unsigned)row << 8) | (unsigned)col;
+                    const int pos = atomicAdd(a.sq_counters + wg, 1);
+                    if (pos < a.sq_cap) a.sq_entries[(size_t)wg * a.sq_cap + pos] = ((unsigned)row << 8) | (unsigned)col;
                     else *a.sq_overflow = 1;
                     return;
                 }
@@ -836,6 +839,41 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeA
 #endif
 }
 
+template <class C, int MODE, bool KALIGNED, bool DMA, bool LLDS, bool BF16>
+__global__ __launch_bounds__(C::NT, C::OCC) void encode_f32_kernel(const EncodeArgs a) {
+    encode_body<C, MODE, KALIGNED, DMA, LLDS, BF16>(a, blockIdx.x);
+}
+
+// The bf16 SPARSE emit (the screen of the lens pass) of SEVERAL dictionaries on the same number of rows in one launch:
+// at CircuitLens sizes one dictionary's emit is 768 single-tile workgroups on 512 resident slots -- 1.5 rounds, each
+// workgroup a chain of exposed latencies -- and emits on different streams do not pack into each other's idle half
+// round; one grid over all of them does.  What differs per dictionary travels in the kernel arguments.
+constexpr int GROUP_MAX = 32;
+struct EmitGroupArgs {
+    struct One {
+        const void *x, *Wt;                  // bf16(x - b_dec) [M][K] (the handle's staging), bf16(W_enc) transposed [N][K]
+        const float *bias, *wnorm, *bound;   // b_enc, column norms, the row bound of this call
+        int *sp_feat, *sp_count;
+        float *sp_val;
+        int N, n_tiles_n, wg_end;            // wg_end: first workgroup of the NEXT problem
+    } d[GROUP_MAX];
+    long long M;
+    int K, max_active, m_split, n;
+};
+template <class C>
+__global__ __launch_bounds__(C::NT, C::OCC) void encode_group_kernel(const EmitGroupArgs g) {
+    int p = 0;  // uniform: the problem's fields are scalar loads
+    while (p + 1 < g.n && (int)blockIdx.x >= g.d[p].wg_end) ++p;
+    const int wg0 = p ? g.d[p - 1].wg_end : 0;
+    EncodeArgs a = {};
+    a.x = (const float *)g.d[p].x; a.Wt = (const float *)g.d[p].Wt; a.bias = g.d[p].bias;
+    a.screen_wnorm = g.d[p].wnorm; a.screen_bound = g.d[p].bound;
+    a.sp_feat = g.d[p].sp_feat; a.sp_val = g.d[p].sp_val; a.sp_count = g.d[p].sp_count;
+    a.N = g.d[p].N; a.n_tiles_n = g.d[p].n_tiles_n;
+    a.M = g.M; a.K = g.K; a.max_active = g.max_active; a.m_split = g.m_split;
+    encode_body<C, TSC_MODE_SPARSE, true, true, false, true>(a, (int)blockIdx.x - wg0);
+}
+
 // bias[n] = b_enc[n] - sum_k b_dec[k] * W[k,n], summed in fp64 and rounded once: lets the DMA kernel
 // contract the raw x (relu((x - b_dec) @ W + b_enc) == relu(x @ W + bias) up to fp32 rounding).
 __global__ __launch_bounds__(256) void fold_bias_kernel(const float *__restrict__ W, const float *__restrict__ b_enc,
@@ -966,6 +1004,35 @@ int tsc_launch_fold_bias(const float *W, const float *b_enc, const float *b_dec,
 int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream) {
     if (a.M <= 0) return TSC_OK;
     return pick_large(mode, a) ? dispatch<CfgLarge>(mode, a, stream) : dispatch<CfgSmall>(mode, a, stream);
+}
+
+// grouped bf16 screen emit: `n` problems that share M, K and max_active; p[i] carries the per-dictionary pointers
+int tsc_launch_emit_group(int n, const EmitGroupProblem *p, long long M, int K, int max_active, hipStream_t stream) {
+    if (n <= 0 || M <= 0) return TSC_OK;
+    if (n > GROUP_MAX) return tsc_fail(TSC_ERR_UNSUPPORTED, "at most %d dictionaries per grouped emit (got %d)", GROUP_MAX, n);
+    if (K % 128 != 0) return tsc_fail(TSC_ERR_UNSUPPORTED, "grouped bf16 emit needs d_in %% 128 == 0");
+    // the wide tile: a grouped grid has no round quantisation (ungrouped, 192 wide tiles on 256 CUs lose to 768 small
+    // ones on 512 slots), and a wide-tile k-step does four times the work of a small one for about the same latency
+    typedef CfgLarge C;
+    EmitGroupArgs g;
+    memset(&g, 0, sizeof(g));
+    const long long n_mtiles = (M + C::BM - 1) / C::BM;
+    g.M = M; g.K = K; g.max_active = max_active; g.n = n;
+    g.m_split = (int)(n_mtiles < 8 ? n_mtiles : 8);
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        if ((unsigned long long)p[i].N * K * 2 + 8192ull >= (1ull << 32))
+            return tsc_fail(TSC_ERR_UNSUPPORTED, "bf16 encode needs d_in * d_sae * 2 < 4 GiB");
+        g.d[i].x = p[i].x_bf16; g.d[i].Wt = p[i].W_bf16; g.d[i].bias = p[i].b_enc; g.d[i].wnorm = p[i].wnorm;
+        g.d[i].bound = p[i].bound; g.d[i].sp_feat = p[i].feat; g.d[i].sp_val = p[i].val; g.d[i].sp_count = p[i].count;
+        g.d[i].N = p[i].N; g.d[i].n_tiles_n = (p[i].N + C::BN - 1) / C::BN;
+        total += (long long)g.d[i].n_tiles_n * g.m_split;
+        g.d[i].wg_end = (int)total;
+    }
+    if (total > 0x7fffffffLL) return tsc_fail(TSC_ERR_UNSUPPORTED, "grouped emit grid out of range");
+    hipLaunchKernelGGL((encode_group_kernel<C>), dim3((unsigned)total), dim3(C::NT), 0, stream, g);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
 }
 
 int tsc_encode_tile_bn(int mode, const EncodeArgs &a) { return pick_large(mode, a) ? CfgLarge::BN : CfgSmall::BN; }

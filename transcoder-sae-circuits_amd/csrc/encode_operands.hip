@@ -16,6 +16,8 @@
 //   * x per call: (x - b_dec) rounded to bf16 into a handle-owned workspace of TSC_BF16_WS_ROWS rows; longer
 //     inputs are processed in chunks of that many rows (stream order makes the reuse safe; calls on one bf16
 //     handle must therefore not overlap on different streams).
+#include <cstring>
+
 #include "tsc_internal.h"
 
 namespace {
@@ -68,6 +70,29 @@ __global__ __launch_bounds__(256) void convert_x_kernel(const float *__restrict_
     u.h[4] = f32_to_bf16_rne(a1.x - b1.x); u.h[5] = f32_to_bf16_rne(a1.y - b1.y);
     u.h[6] = f32_to_bf16_rne(a1.z - b1.z); u.h[7] = f32_to_bf16_rne(a1.w - b1.w);
     *(uint4 *)(out + i * 8) = u.v;
+}
+
+// the same for several (x, b_dec, out) triples of one shape in one launch: grid.y = the triple
+struct ConvertGroupArgs {
+    const float *x[32], *b_dec[32];
+    unsigned short *out[32];
+    long long n8;
+    int K8;
+};
+__global__ __launch_bounds__(256) void convert_x_group_kernel(const ConvertGroupArgs g) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.n8) return;
+    const int p = blockIdx.y;  // uniform
+    const float *x = g.x[p], *b_dec = g.b_dec[p];
+    const int k0 = (int)(i % g.K8) * 8;
+    const float4 a0 = *(const float4 *)(x + i * 8), a1 = *(const float4 *)(x + i * 8 + 4);
+    const float4 b0 = *(const float4 *)(b_dec + k0), b1 = *(const float4 *)(b_dec + k0 + 4);
+    union { unsigned short h[8]; uint4 v; } u;
+    u.h[0] = f32_to_bf16_rne(a0.x - b0.x); u.h[1] = f32_to_bf16_rne(a0.y - b0.y);
+    u.h[2] = f32_to_bf16_rne(a0.z - b0.z); u.h[3] = f32_to_bf16_rne(a0.w - b0.w);
+    u.h[4] = f32_to_bf16_rne(a1.x - b1.x); u.h[5] = f32_to_bf16_rne(a1.y - b1.y);
+    u.h[6] = f32_to_bf16_rne(a1.z - b1.z); u.h[7] = f32_to_bf16_rne(a1.w - b1.w);
+    *(uint4 *)(g.out[p] + i * 8) = u.v;
 }
 
 // wnorm[n] = ||W[:, n]||_2, summed in fp64 and rounded UP (it scales an error bound)
@@ -158,6 +183,31 @@ int tsc_pack_w_bf16(const float *W, int K, int N, void *dst, hipStream_t stream)
 int tsc_transpose_w_f32(const float *W, int K, int N, float *dst, hipStream_t stream) {
     if (K % 8) return tsc_fail(TSC_ERR_UNSUPPORTED, "W_enc transpose needs d_in %% 8 == 0");
     hipLaunchKernelGGL(transpose_w_kernel, dim3((N + 255) / 256, K / 8), dim3(256), 0, stream, W, K, N, dst);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
+int tsc_launch_convert_x_bf16(const float *x, const float *b_dec, long long rows, int K, void *x_bf16, hipStream_t stream) {
+    if (rows <= 0) return TSC_OK;
+    if (rows > TSC_BF16_WS_ROWS) return tsc_fail(TSC_ERR_UNSUPPORTED, "the bf16 staging buffer holds %d rows", (int)TSC_BF16_WS_ROWS);
+    const long long n8 = rows * (K / 8);
+    hipLaunchKernelGGL(convert_x_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, x, b_dec, n8, K / 8,
+                       (unsigned short *)x_bf16);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
+int tsc_launch_convert_x_bf16_group(int n, const float *const *x, const float *const *b_dec, void *const *x_bf16,
+                                    long long rows, int K, hipStream_t stream) {
+    if (rows <= 0 || n <= 0) return TSC_OK;
+    if (n > 32) return tsc_fail(TSC_ERR_UNSUPPORTED, "at most 32 inputs per grouped conversion");
+    if (rows > TSC_BF16_WS_ROWS) return tsc_fail(TSC_ERR_UNSUPPORTED, "the bf16 staging buffer holds %d rows", (int)TSC_BF16_WS_ROWS);
+    ConvertGroupArgs g;
+    memset(&g, 0, sizeof(g));
+    for (int i = 0; i < n; ++i) { g.x[i] = x[i]; g.b_dec[i] = b_dec[i]; g.out[i] = (unsigned short *)x_bf16[i]; }
+    g.n8 = rows * (K / 8);
+    g.K8 = K / 8;
+    hipLaunchKernelGGL(convert_x_group_kernel, dim3((unsigned)((g.n8 + 255) / 256), (unsigned)n), dim3(256), 0, stream, g);
     TSC_HIP_CHECK(hipGetLastError());
     return TSC_OK;
 }

@@ -62,6 +62,17 @@ struct EncodeArgs {
     const int *run_flag;  // when set: the whole launch returns at once unless *run_flag != 0 (the fp32 fallback of the screen)
 };
 int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream);  // a.m_split <= 0: balanced
+struct EmitGroupProblem {  // one dictionary of a grouped bf16 screen emit (encode_f32.hip: tsc_launch_emit_group)
+    const void *x_bf16, *W_bf16;
+    const float *b_enc, *wnorm, *bound;
+    int *feat, *count;
+    float *val;
+    int N;
+};
+int tsc_launch_emit_group(int n, const EmitGroupProblem *p, long long M, int K, int max_active, hipStream_t stream);
+int tsc_launch_convert_x_bf16(const float *x, const float *b_dec, long long rows, int K, void *x_bf16, hipStream_t stream);
+int tsc_launch_convert_x_bf16_group(int n, const float *const *x, const float *const *b_dec, void *const *x_bf16,
+                                    long long rows, int K, hipStream_t stream);
 int tsc_encode_recommended_slots(int d_sae, int bf16);
 int tsc_encode_tile_bn(int mode, const EncodeArgs &a);  // column-tile width the launcher will pick for these arguments
 int tsc_encode_set_tuning(const char *key, int value);
