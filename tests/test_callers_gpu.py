@@ -488,14 +488,15 @@ def test_module_copies_drop_handles_and_autograd_is_refused():
         _close(tc.encode(x.to(DEV)), g["tc_encode"])  # inputs that do not require grad are fine with grad mode on
 
 
-@pytest.mark.parametrize("screened", [False, True])
-def test_grouped_finish_equals_the_per_dictionary_lens_pass(screened):
+@pytest.mark.parametrize("screened,m", [(False, 77), (True, 77), (True, 3000)])
+def test_grouped_finish_equals_the_per_dictionary_lens_pass(screened, m):
     """``tsc_sparse_lens_finish_many`` after ``TSC_LENS_EMIT_ONLY`` emits: the same kernel body over the rows of
-    several dictionaries in one launch -- results bit for bit those of ``tsc_sparse_lens_pass`` per dictionary."""
+    several dictionaries in one launch -- results bit for bit those of ``tsc_sparse_lens_pass`` per dictionary; and
+    ``tsc_sparse_lens_emit_many`` (screening handles: ONE grouped launch of the emits) in front of it."""
     import tsc_hip
     from standins.synthetic_dicts import make_dictionary_weights
 
-    m, cap, n = 77, 512, 3
+    cap, n = 512, 3   # m = 3000: twelve 256-row tiles, every workgroup of the grouped emit walks several
     ws = [make_dictionary_weights(768, d_sae, seed=60 + i, b_enc=-1.0) for i, d_sae in enumerate((1536, 1000, 4100))]
     hs = [_dd(w, compute_dtype=tsc_hip.F32_SCREEN if screened else tsc_hip.F32)[0] for w in ws]
     gen = torch.Generator().manual_seed(8)
