@@ -73,20 +73,39 @@ class HipDictionaryMixin:
         """The library handle for the current parameter storage: fp32, the bf16-MFMA variant, or (``screened``)
         the fp32 handle that also carries the operands of the lens pass' bf16 screen -- fp32 results from every
         entry point; dictionaries whose ``d_in`` is not a multiple of 128 get the plain fp32 handle."""
+        try:  # fast path (this runs once per dictionary and call): same parameter storage as when the handle was made
+            prm = self._parameters
+            W_enc, b_enc, b_dec, W_dec, ob = prm["W_enc"], prm["b_enc"], prm["b_dec"], prm["W_dec"], self._out_bias()
+            if screened and (bf16 or W_enc.shape[0] % 128 != 0 or W_dec.shape[1] > 768):
+                screened = False
+            attr = "_hip_bf16" if bf16 else "_hip_screen" if screened else "_hip"
+            inst = self.__dict__
+            if attr == "_hip" and inst.get("_hip") is None and inst.get("_hip_screen") is not None:
+                attr = "_hip_screen"  # a screening handle does everything a plain fp32 handle does: do not keep two
+            cur = inst.get(attr)
+            if cur is not None and cur.__dict__.get("_param_key") == (W_enc.data_ptr(), b_enc.data_ptr(), b_dec.data_ptr(),
+                                                                      W_dec.data_ptr(), ob.data_ptr()):
+                cur.refresh_if_modified()
+                return cur
+        except (KeyError, AttributeError):
+            pass
         self._require_gpu_fp32()
         if screened and (bf16 or self.W_enc.shape[0] % 128 != 0 or self.W_dec.shape[1] > 768):
             screened = False
-        tensors = (self.W_enc.detach(), self.b_enc.detach(), self.b_dec.detach(), self.W_dec.detach(), self._out_bias().detach())
+        originals = (self.W_enc, self.b_enc, self.b_dec, self.W_dec, self._out_bias())
+        tensors = tuple(t.detach() for t in originals)
         tensors = tuple(t if t.is_contiguous() else t.contiguous() for t in tensors)
         attr = "_hip_bf16" if bf16 else "_hip_screen" if screened else "_hip"
         if attr == "_hip" and self._hip is None and self._hip_screen is not None:
-            attr = "_hip_screen"  # a screening handle does everything a plain fp32 handle does: do not keep two
+            attr = "_hip_screen"
         cur = getattr(self, attr)
         if cur is None or not cur.same_storage(*tensors):
             if cur is not None:
                 cur.close()
             cur = tsc_hip.DeviceDict(*tensors, compute_dtype=tsc_hip.BF16 if bf16 else
                                      tsc_hip.F32_SCREEN if screened else tsc_hip.F32)
+            if all(a.data_ptr() == b.data_ptr() for a, b in zip(originals, tensors)):  # no contiguous copies were needed
+                cur._param_key = tuple(t.data_ptr() for t in originals)
             object.__setattr__(self, attr, cur)
         else:
             cur.refresh_if_modified()
