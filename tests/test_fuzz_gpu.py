@@ -13,7 +13,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("tool,seed,cases", [("fuzz_topk.py", 11, 500), ("fuzz_screened.py", 12, 150), ("fuzz_lens.py", 13, 300),
-                                             ("fuzz_merge.py", 14, 500), ("fuzz_encode.py", 15, 1000), ("fuzz_aux.py", 16, 1000)])
+                                             ("fuzz_merge.py", 14, 500), ("fuzz_encode.py", 15, 1000), ("fuzz_aux.py", 16, 1000), ("fuzz_grouped.py", 17, 300)])
 def test_randomised_list_checks(tool, seed, cases):
     """A fixed number of cases from a fixed seed (the same cases on every machine); the time budget is only a guard."""
     p = subprocess.run([sys.executable, os.path.join(REPO, "tools", tool), "90", str(seed), str(cases)],
