@@ -394,12 +394,39 @@ def measured_traffic():
 
 
 # ----------------------------------------------------------------------------- launcher
+def visible_gpu_count(sysfs_root="/sys/class/kfd/kfd/topology/nodes"):
+    """Number of GPUs a child process would see, WITHOUT touching the HIP runtime (no ``torch.cuda`` call: on ROCm
+    ``device_count()`` resolves to ``hipGetDeviceCount``, which opens the devices, and a process that has done so
+    must not start children that exec).  The visibility lists (``ROCR_VISIBLE_DEVICES``, ``HIP_VISIBLE_DEVICES``,
+    ``CUDA_VISIBLE_DEVICES``: each narrows the previous one) win when set; otherwise the KFD topology in sysfs is
+    counted: a node with ``simd_count > 0`` is a GPU (CPU nodes have 0)."""
+    import glob
+
+    on_host = 0
+    for path in glob.glob(os.path.join(sysfs_root, "*", "properties")):
+        try:
+            for line in open(path):
+                parts = line.split()
+                if len(parts) == 2 and parts[0] == "simd_count" and int(parts[1]) > 0:
+                    on_host += 1
+        except (OSError, ValueError):
+            continue
+    have = on_host
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = os.environ.get(var)
+        if val is not None:
+            listed = len([v for v in val.split(",") if v.strip() != ""])
+            have = min(have, listed) if on_host else listed
+    return have
+
+
 def launch_ranks(args, argv):
-    """Parent of an N > 1 run: starts N rank processes and relays their exit status.  Makes no GPU call
-    (``torch.cuda.device_count()`` does not initialise the runtime on this image)."""
+    """Parent of an N > 1 run: starts N FRESH rank processes and relays their exit status.  The parent makes no
+    GPU call of any kind -- the device count comes from the environment / sysfs (``visible_gpu_count``), never from
+    ``torch.cuda`` -- so no process that has initialised the GPU ever spawns or execs another."""
     n = args.gpus
     if args.engine_module is None and not args.rehearse_on_one_gpu:
-        have = torch.cuda.device_count()
+        have = visible_gpu_count()
         if have < n:
             print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible; refusing to report a "
                   f"{have}-GPU number as a {n}-GPU one (use --rehearse-on-one-gpu to rehearse the N-rank path on one GPU)",
@@ -411,6 +438,23 @@ def launch_ranks(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode
+
+
+def init_collectives(dist, backend, device, rank, world, timeout_s):
+    """``init_process_group`` with a finite timeout; a rank that cannot join says which rank it is and what the
+    backend reported before it exits non-zero (an RCCL failure otherwise surfaces as a hang of the other ranks)."""
+    import datetime
+
+    try:
+        kw = {"timeout": datetime.timedelta(seconds=timeout_s)}
+        if backend == "nccl":
+            kw["device_id"] = device
+        dist.init_process_group(backend, **kw)
+        dist.barrier()  # the first collective creates the communicator: fail here, with a name, not mid-run
+    except Exception as e:  # noqa: BLE001
+        print(f"bench.py: rank {rank} of {world} ({backend} on {device}) could not join the process group: "
+              f"{type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        raise SystemExit(4)
 
 
 def parse_args(argv):
@@ -434,6 +478,7 @@ def parse_args(argv):
     # with --gpus 1: still create the nccl (RCCL) process group (world size 1) and run every collective of the
     # N > 1 path on the device -- the code-path check a one-GPU box allows for the RCCL branch
     ap.add_argument("--exercise-collectives", action="store_true")
+    ap.add_argument("--collective-timeout", type=int, default=300, help="seconds; process-group init and collectives")
     # tests only: comma-separated dictionary widths instead of the config's 24, and a stand-in engine module
     ap.add_argument("--dict-widths", default=None)
     ap.add_argument("--engine-module", default=None)
@@ -475,12 +520,7 @@ def main(argv=None):
             os.environ.setdefault("MASTER_PORT", "29541")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        if host_collectives:
-            import datetime
-
-            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
-        else:
-            dist.init_process_group("nccl", device_id=device)
+        init_collectives(dist, "gloo" if host_collectives else "nccl", device, rank, world, args.collective_timeout)
 
     B, K, W = args.tokens_per_step, args.steps, args.warmup
     if args.dict_widths:

@@ -245,13 +245,14 @@ int tsc_contrib_scores(const tsc_dict_t *dict, const int32_t *feat, const float 
  * On a TSC_F32_SCREEN handle the emit is a two-stage EXACT computation: (1) the bf16 MFMA kernel (16x the fp32
  * matrix rate) computes bf16(x - b_dec) @ bf16(W_enc) + b_enc + margin[n] and emits every feature for which that
  * is positive -- margin[n] = bound * ||W_enc[:, n]||_2 + 2 d_in 2^-24 |b_enc[n]| is a proven bound of the difference
- * between the exact fp32 pre-activation and the bf16 one (both bf16 roundings through Cauchy-Schwarz, plus the fp32
+ * between the exact fp32 pre-activation and the bf16 one (both bf16 roundings, up to 2^-8 relative each, through
+ * Cauchy-Schwarz, plus the fp32
  * accumulation error of both sums), so no feature with a positive exact activation is missed; (2) the second
  * kernel recomputes each candidate exactly in fp32 (dot(x, W_enc^T[f]) + bias') and keeps the positive ones.
  * Values are fp32 values (summed in a different order than tsc_encode_dense: they agree to ~1e-7 relative, and a
  * feature whose pre-activation is within that of zero may be active in one and not the other).  count[m] above
  * max_active then means "the CANDIDATES overflowed" (an upper bound of the active count): retry with that capacity.
- * screen_row_bound: device pointer to ONE float >= (2^-8 * 1.01 + g) max_m ||x_m - b_dec|| + g (max_m ||x_m|| +
+ * screen_row_bound: device pointer to ONE float >= (2^-7 * 1.01 + g) max_m ||x_m - b_dec|| + g (max_m ||x_m|| +
  * ||b_dec||), g = 2 d_in 2^-24, or NULL = the library computes it (one more small kernel); ignored by other
  * handles.  At most 32768 rows per call on such a handle.
  */
@@ -272,7 +273,8 @@ int tsc_sparse_lens_pass(const tsc_dict_t *dict, const float *x, int64_t M, int 
  * each other's idle half round -- one grid over all dictionaries does.  Otherwise dictionary i runs on
  * streams[i % n_streams].  Either way the caller orders ALL the streams before and after.  dicts, x,
  * screen_row_bounds (or NULL), streams: HOST arrays.  flags as tsc_sparse_lens_pass.  Results are those of the
- * separate calls (the order in which a row's pairs are emitted is unspecified either way).
+ * separate calls (the order in which a row's pairs are emitted is unspecified either way).  Every handle may appear
+ * ONCE (a handle's staging buffer serves one problem at a time): a repeated handle is refused with TSC_ERR_ARG.
  */
 int tsc_sparse_lens_emit_many(int n_dicts, const tsc_dict_t *const *dicts, const float *const *x, int64_t M,
                               int max_active, int32_t *feat, float *val, int32_t *count, int flags,

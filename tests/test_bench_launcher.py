@@ -12,13 +12,14 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(extra, timeout=300):
+def _run(extra, timeout=300, script=None, env_extra=None):
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     env["PYTHONPATH"] = HERE + os.pathsep + env.get("PYTHONPATH", "")
     env["MASTER_PORT"] = str(29900 + os.getpid() % 1500)
-    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + extra, env=env, capture_output=True,
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, script or os.path.join(REPO, "bench.py")] + extra, env=env, capture_output=True,
                           text=True, timeout=timeout)
 
 
@@ -69,3 +70,45 @@ def test_exercise_collectives_at_world_size_one():
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["verified"] is True and out["lists_identical_on_all_ranks"] is True
     assert "world size 1" in out["collective_backend"]
+
+
+def test_launcher_parent_never_touches_torch_cuda():
+    """Round-2 verdict: the parent of an N > 1 run must not call into ``torch.cuda`` at all (on ROCm even
+    ``device_count()`` opens the device, and a GPU-initialised process must not start children that exec).  The
+    parent here runs with every such entry patched to raise: the 2-rank gloo run still completes and the refusal of
+    a too-large ``--gpus`` still comes from the sysfs / environment count."""
+    helper = os.path.join(HERE, "parent_without_torch_cuda.py")
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--tokens-per-step", "128", "--dict-widths", "96",
+              "--k", "5", "--engine-module", "cpu_bench_engine", "--no-cpu-baseline"], script=helper)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["verified"] is True
+    # refusal: the visibility list names one device, two are asked for
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], script=helper, timeout=120,
+             env_extra={"HIP_VISIBLE_DEVICES": "0"})
+    assert p.returncode == 2, (p.returncode, p.stderr[-500:])
+    assert "only 1 GPU(s) are visible" in p.stderr and "touched torch.cuda" not in p.stderr
+
+
+def test_visible_gpu_count_reads_sysfs_and_visibility_lists(tmp_path, monkeypatch):
+    sys.path.insert(0, REPO)
+    import bench
+
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024, 1024]):  # two CPU nodes, four GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nmem_banks_count 1\n")
+    (tmp_path / "6").mkdir()  # a node without a readable properties file is skipped
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpu_count(str(tmp_path)) == 4
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
+    assert bench.visible_gpu_count(str(tmp_path)) == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "2")
+    assert bench.visible_gpu_count(str(tmp_path)) == 1
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count(str(tmp_path)) == 0
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2,3,4,5,6,7")   # a list longer than the host: the host wins
+    assert bench.visible_gpu_count(str(tmp_path)) == 4
+    assert bench.visible_gpu_count(str(tmp_path / "missing")) == 8  # no sysfs: trust the list

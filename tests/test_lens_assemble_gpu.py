@@ -155,3 +155,30 @@ def test_lens_assemble_zero_rows():
     out = tsc_hip.lens_assemble(torch.zeros(0, 2, device=DEV), torch.zeros(0, 2, device=DEV), [1, 1],
                                 torch.zeros(2, 0, 8, device=DEV), torch.zeros(2, 0, dtype=torch.int32, device=DEV), k=3)
     assert out["top_values"].shape == (0, 3) and out["top_info"].shape == (0, 3, 4) and out["activations"].shape == (0, 20)
+
+
+@pytest.mark.parametrize("cap", [64, 2048])  # a row that is ranked out of LDS, and one that is too wide for it
+def test_lens_assemble_live_minus_infinity_is_live_on_both_paths(cap):
+    """Round-2 advisor: liveness must not be carried by a value.  A LIVE score of -inf (a masked score) stays live in
+    ``mask`` and is divided like any other value, whether the row goes through LDS or not; dead slots read 0."""
+    import tsc_hip
+
+    G, R, k = 24, 4, 5
+    group_aux = [3, 2] * 12
+    g = torch.Generator(device=DEV).manual_seed(cap)
+    scores = torch.rand(G, R, cap, generator=g, device=DEV)
+    count = torch.full((G, R), cap // 2, dtype=torch.int32, device=DEV)
+    scores[3, 1, 2] = float("-inf")          # live (slot 2 < count), row 1
+    scores[5, 2, cap - 1] = float("-inf")    # dead slot, row 2: must not matter
+    head = torch.rand(R, 2, generator=g, device=DEV) + 10
+    aux = torch.rand(R, sum(group_aux), generator=g, device=DEV)
+    out = tsc_hip.lens_assemble(head, aux, group_aux, scores, count, k=k, dense=True)
+    raw, acts, mask, v, c = _reference(head, aux, group_aux, scores, count, k)
+    assert torch.equal(out["mask"], mask) and torch.equal(out["raw"], raw)
+    cols, W = _layout(2, group_aux, cap)
+    col = cols[3][0] + group_aux[3] + 2
+    assert bool(out["mask"][1, col]) and float(out["raw"][1, col]) == float("-inf")
+    assert float(out["activations"][1, col]) != 0.0          # -inf / -inf = NaN: divided, not zeroed as a dead slot is
+    for r in (0, 2, 3):                                      # the other rows are ordinary
+        torch.testing.assert_close(out["activations"][r], acts[r], rtol=2e-5, atol=1e-9)
+        assert torch.equal(out["top_columns"][r].long(), c[r])

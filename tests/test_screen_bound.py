@@ -56,7 +56,36 @@ def test_screen_margin_bounds_the_bf16_error():
         assert bool(((approx + margin[None, :]) > 0)[acts > 0].all())
         # and the screen stays selective on ordinary inputs
         if w is cases[0][0]:
-            assert float(((approx + margin[None, :]) > 0).float().mean()) < 2.0 * float((acts > 0).float().mean()) + 1e-4
+            assert float(((approx + margin[None, :]) > 0).float().mean()) < 2.5 * float((acts > 0).float().mean()) + 1e-4
+
+
+def test_screen_margin_holds_at_bf16_rounding_midpoints():
+    """Adversarial case (round-2 advisor): every operand sits on a bf16 rounding midpoint with aligned signs, so BOTH
+    roundings of every product lose the full 2^-8 and nothing cancels: the exact pre-activation is +0.5 while the
+    screened one is about -5.5.  A margin built on 2^-9 per rounding drops this active feature; 2^-8 per rounding
+    (2^-7 per product) keeps it."""
+    K, N = 768, 64
+    gen = torch.Generator().manual_seed(5)
+    mid = 1.0 + 2.0 ** -8                      # ties-to-even rounds it DOWN to 1.0: relative error 2^-8 / (1 + 2^-8)
+    sign = torch.where(torch.rand(K, generator=gen) < 0.5, -1.0, 1.0)
+    x = (mid * sign)[None, :].repeat(2, 1)
+    x[1] = (1.0 + 3 * 2.0 ** -8) * sign       # the other tie direction: rounds UP to 1 + 2^-6
+    W = (mid * sign)[:, None].repeat(1, N) * (2.0 ** torch.arange(-8, 8).repeat(N // 16))[None, :]  # exact scalings
+    b_dec = torch.zeros(K)
+    exact = (x.double() @ W.double())
+    b_enc = (-(exact[0]) + 0.5).float()       # row 0 is active by +0.5 in every column
+    w = {"W_enc": W, "b_enc": b_enc, "b_dec": b_dec}
+    margin = _margin(x, w)
+    approx = _pre_bf16(x, w)
+    pre64 = exact + b_enc.double()
+    assert bool((pre64[0] > 0).all())
+    # the old coefficient (half this margin) would have lost the wide columns
+    assert float((approx[0] + 0.5 * margin).min()) < 0
+    err = (pre64.float() - approx).abs()
+    assert bool((err <= margin[None, :]).all()), float((err / margin[None, :]).max())
+    assert bool(((approx + margin[None, :]) > 0)[pre64 > 0].all())
+    # and the bound is nearly attained here (nothing to give away): within 2 % of the worst row
+    assert float((err / margin[None, :]).max()) > 0.9
 
 
 def test_prompt_cache_view_slices_like_a_single_prompt_cache():

@@ -76,21 +76,21 @@ class HipDictionaryMixin:
         try:  # fast path (this runs once per dictionary and call): same parameter storage as when the handle was made
             prm = self._parameters
             W_enc, b_enc, b_dec, W_dec, ob = prm["W_enc"], prm["b_enc"], prm["b_dec"], prm["W_dec"], self._out_bias()
-            if screened and (bf16 or W_enc.shape[0] % 128 != 0 or W_dec.shape[1] > 768):
-                screened = False
+            if screened and (bf16 or W_enc.shape[0] % 128 != 0 or W_enc.shape[0] > 768 or W_dec.shape[1] > 768):
+                screened = False  # the screened finish kernel holds a row of <= 768 inputs in registers
             attr = "_hip_bf16" if bf16 else "_hip_screen" if screened else "_hip"
             inst = self.__dict__
             if attr == "_hip" and inst.get("_hip") is None and inst.get("_hip_screen") is not None:
                 attr = "_hip_screen"  # a screening handle does everything a plain fp32 handle does: do not keep two
             cur = inst.get(attr)
             if cur is not None and cur.__dict__.get("_param_key") == (W_enc.data_ptr(), b_enc.data_ptr(), b_dec.data_ptr(),
-                                                                      W_dec.data_ptr(), ob.data_ptr()):
+                                                                      W_dec.data_ptr(), ob.data_ptr(), W_enc.shape, W_dec.shape):
                 cur.refresh_if_modified()
                 return cur
         except (KeyError, AttributeError):
             pass
         self._require_gpu_fp32()
-        if screened and (bf16 or self.W_enc.shape[0] % 128 != 0 or self.W_dec.shape[1] > 768):
+        if screened and (bf16 or self.W_enc.shape[0] % 128 != 0 or self.W_enc.shape[0] > 768 or self.W_dec.shape[1] > 768):
             screened = False
         originals = (self.W_enc, self.b_enc, self.b_dec, self.W_dec, self._out_bias())
         tensors = tuple(t.detach() for t in originals)
@@ -105,7 +105,8 @@ class HipDictionaryMixin:
             cur = tsc_hip.DeviceDict(*tensors, compute_dtype=tsc_hip.BF16 if bf16 else
                                      tsc_hip.F32_SCREEN if screened else tsc_hip.F32)
             if all(a.data_ptr() == b.data_ptr() for a, b in zip(originals, tensors)):  # no contiguous copies were needed
-                cur._param_key = tuple(t.data_ptr() for t in originals)
+                # (storage addresses AND shapes: a parameter re-allocated at a freed address with another shape is new)
+                cur._param_key = tuple(t.data_ptr() for t in originals) + (self.W_enc.shape, self.W_dec.shape)
             object.__setattr__(self, attr, cur)
         else:
             cur.refresh_if_modified()

@@ -345,8 +345,8 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
         side = _pass_streams(dev, n_side) if rows <= 8192 and n_d > 1 and n_side > 1 else []
         # ... and, with several dictionaries, stop each after its emit and finish them all in ONE launch
         # (tsc_sparse_lens_finish_many): one dictionary's 512 rows are two workgroups per CU, 24 x 512 fill the chip.
-        grouped = 1 < n_d <= 32 and rows <= 8192 and len({h.compute_dtype for h in handles}) == 1 and \
-            os.environ.get("TSC_LENS_GROUPED", "1") != "0"
+        grouped = 1 < n_d <= 32 and rows <= 8192 and len({(h.compute_dtype, h.d_in, h.d_out) for h in handles}) == 1 and \
+            len({id(h) for h in handles}) == n_d and os.environ.get("TSC_LENS_GROUPED", "1") != "0"
         _mark("pass: buffers ready")
         start = torch.cuda.Event()
         start.record(main)

@@ -371,6 +371,12 @@ int tsc_sparse_lens_emit_many(int n_dicts, const tsc_dict_t *const *dicts, const
     if (n_dicts == 0 || M == 0) return TSC_OK;
     if (!dicts || !x || !feat || !val || !count) return tsc_fail(TSC_ERR_ARG, "null lens_emit_many pointer");
     if (n_streams < 1 || !streams) return tsc_fail(TSC_ERR_ARG, "lens_emit_many needs at least one stream");
+    // a handle listed twice would share its bf16 staging buffer and bound scalar between two problems of one launch
+    // (or race across streams on the fallback below): refused
+    for (int i = 0; i < n_dicts && i < 64; ++i)
+        for (int j = 0; j < i; ++j)
+            if (dicts[i] && dicts[i] == dicts[j])
+                return tsc_fail(TSC_ERR_ARG, "lens_emit_many: dictionary handle %d is listed twice (entries %d and %d)", i, j, i);
     // Screening handles of one input width: ONE grouped launch on streams[0] (a 512-row emit is 1.5 rounds of
     // single-tile workgroups; emits on different streams do not pack into each other's idle half round, one grid does)
     bool group = n_dicts > 1 && n_dicts <= 32 && M <= 32768 && !(flags & TSC_LENS_NO_SCREEN);

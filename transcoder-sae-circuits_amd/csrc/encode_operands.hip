@@ -109,8 +109,9 @@ __global__ __launch_bounds__(256) void col_norm_kernel(const float *__restrict__
 
 // Row bound of the bf16 screen, one wave per row, max over the rows by an atomic on the float's bits (the values
 // are non-negative, so unsigned order is float order):
-//   bound = (2^-8 * 1.01 + g) * ||x - b_dec||_2 + g * (||x||_2 + ||b_dec||_2),  g = 2 * K * 2^-24
-// first term: both bf16 roundings (2^-9 relative each) of every product, Cauchy-Schwarz over the row; second and
+//   bound = (2^-7 * 1.01 + g) * ||x - b_dec||_2 + g * (||x||_2 + ||b_dec||_2),  g = 2 * K * 2^-24
+// first term: both bf16 roundings of every product -- round-to-nearest on an 8-bit significand is up to 2^-8
+// relative EACH, so (1 + e1)(1 + e2) - 1 <= 2^-7 (1 + 2^-9) -- through Cauchy-Schwarz over the row; second and
 // third: the fp32 accumulation error (K * 2^-24 relative to sum |x_k w_k|) of the exact kernel, which contracts the
 // raw x against the folded bias, and of the screen itself.  Multiplied by ||W_enc[:, n]||_2 it bounds
 // |exact pre-activation - screened pre-activation| of column n for every row, up to the g * |b_enc[n]| that the
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void row_bound_kernel(const float *__restrict_
             sc += __shfl_xor(sc, off);
             sr += __shfl_xor(sr, off);
         }
-        best = fmaxf(best, ((0.00390625f * 1.01f + g) * sqrtf(sc) + g * (sqrtf(sr) + nb)) * 1.0001f);
+        best = fmaxf(best, ((0.0078125f * 1.01f + g) * sqrtf(sc) + g * (sqrtf(sr) + nb)) * 1.0001f);
     }
     if (lane == 0) wave_max[wave] = best;
     __syncthreads();

@@ -447,7 +447,9 @@ struct AssembleArgs {
 
 __global__ __launch_bounds__(256) void lens_assemble_kernel(const AssembleArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float *row = (float *)smem_raw;  // [lds_cols] ranked values (dead = -inf) when the row fits
+    float *row = (float *)smem_raw;  // [lds_cols] raw values when the row fits
+    __shared__ unsigned live_bits[(15 * 1024 + 31) / 32];  // ... and which of them are live (a VALUE cannot say: a live
+                                                            // score may be -inf or any other bit pattern)
     __shared__ float red_v[4];
     __shared__ int red_c[4];
     __shared__ float s_total;
@@ -468,8 +470,13 @@ __global__ __launch_bounds__(256) void lens_assemble_kernel(const AssembleArgs p
         part += v;
         if (raw_row) raw_row[c] = v;
         if (mask_row) mask_row[c] = live ? 1 : 0;
-        if (in_lds) row[c] = live ? v : NINF;  // the raw value for now; scaled in pass 2
+        if (in_lds) {
+            row[c] = v;  // the raw value for now; scaled in pass 2
+            if (live) atomicOr(&live_bits[c >> 5], 1u << (c & 31));
+        }
     };
+    if (in_lds)
+        for (int i = tid; i < (p.W + 31) / 32; i += 256) live_bits[i] = 0u;
     if (tid < p.n_groups) {
         const int cnt = p.count[(long long)tid * p.R + r];
         s_cnt[tid] = cnt > p.cap ? p.cap : cnt;
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(256) void lens_assemble_kernel(const AssembleArgs p
             vals[i] = NINF;
             if (c < p.W) {
                 const float v = row[c];
-                const bool live = v != NINF;
+                const bool live = (live_bits[c >> 5] >> (c & 31)) & 1u;
                 const float a = live ? v / total : 0.f;
                 if (acts_row) acts_row[c] = a;
                 if (live) vals[i] = a;

@@ -395,12 +395,12 @@ def sparse_lens_finish_many(handles, inputs, feat: torch.Tensor, val: torch.Tens
 
 def screen_row_bound(x: torch.Tensor, b_dec: torch.Tensor) -> torch.Tensor:
     """The ``screen_row_bound`` of ``tsc_sparse_lens_pass`` (include/tsc_hip.h) for rows ``x [..., M, d_in]``: a
-    device tensor ``[...]`` of ``(2^-8 * 1.01 + g) max_m ||x_m - b_dec|| + g (max_m ||x_m|| + ||b_dec||)``,
+    device tensor ``[...]`` of ``(2^-7 * 1.01 + g) max_m ||x_m - b_dec|| + g (max_m ||x_m|| + ||b_dec||)``,
     ``g = 2 d_in 2^-24``, rounded up.  Leading axes batch over dictionaries (``b_dec [..., d_in]``)."""
     g = 2.0 * x.shape[-1] * 2.0 ** -24
     centred = (x - b_dec.unsqueeze(-2)).norm(dim=-1).amax(dim=-1)
     raw = x.norm(dim=-1).amax(dim=-1)
-    return (((2.0 ** -8 * 1.01 + g) * centred + g * (raw + b_dec.norm(dim=-1))) * 1.0001).to(torch.float32).contiguous()
+    return (((2.0 ** -7 * 1.01 + g) * centred + g * (raw + b_dec.norm(dim=-1))) * 1.0001).to(torch.float32).contiguous()
 
 
 def lens_assemble(head: torch.Tensor, aux: torch.Tensor, group_aux, scores: torch.Tensor, count: torch.Tensor,
@@ -438,12 +438,13 @@ def lens_assemble(head: torch.Tensor, aux: torch.Tensor, group_aux, scores: torc
         out["mask"] = torch.empty(R, W, dtype=torch.bool, device=dev)
     ga = (ctypes.c_int32 * G)(*group_aux)
     ptr = lambda n: out[n].data_ptr() if n in out else None  # noqa: E731
-    _check(lib().tsc_lens_assemble(R, head.shape[1], G, ga, cap, head.data_ptr() if head.numel() else None,
-                                   aux.data_ptr() if aux.numel() else None, scores.data_ptr(), count.data_ptr(),
-                                   column_tags.data_ptr() if column_tags is not None else None,
-                                   feat.data_ptr() if feat is not None else None, k,
-                                   ptr("raw"), ptr("activations"), ptr("mask"), out["top_values"].data_ptr(),
-                                   out["top_info"].data_ptr(), _stream()))
+    with torch.cuda.device(dev):
+        _check(lib().tsc_lens_assemble(R, head.shape[1], G, ga, cap, head.data_ptr() if head.numel() else None,
+                                       aux.data_ptr() if aux.numel() else None, scores.data_ptr(), count.data_ptr(),
+                                       column_tags.data_ptr() if column_tags is not None else None,
+                                       feat.data_ptr() if feat is not None else None, k,
+                                       ptr("raw"), ptr("activations"), ptr("mask"), out["top_values"].data_ptr(),
+                                       out["top_info"].data_ptr(), _stream()))
     out["top_columns"] = out["top_info"][:, :, 0]
     return out
 
