@@ -130,7 +130,7 @@ def test_screened_topk_with_non_finite_rows_matches_the_fp32_path():
     assert not bool((ri == 1200).any()) and not bool((ri == 17).any())   # NaN rows are in no list
 
 
-def _midpoint_case(n_rows=640, d_sae=1536, seed=9):
+def _midpoint_case(n_rows=640, d_sae=1536, seed=9, exps=(-6, 6)):
     """Operands on bf16 rounding midpoints with aligned signs (round-2 advisor's counter-example): each product loses
     the full 2^-7 in the screen and nothing cancels.  Rows ``hot`` carry exactly the sign pattern of the columns:
     their exact pre-activation is +0.5 in every column while the bf16 one is about -5.5 * 2^e of the column."""
@@ -141,13 +141,13 @@ def _midpoint_case(n_rows=640, d_sae=1536, seed=9):
     mid = 1.0 + 2.0 ** -8
     sign = torch.where(torch.rand(K, generator=gen) < 0.5, -1.0, 1.0)
     w = make_dictionary_weights(K, d_sae, seed=seed, b_enc=0.0)
-    scale = 2.0 ** torch.arange(-6, 6).repeat(d_sae // 12)
+    scale = 2.0 ** torch.arange(*exps).repeat(d_sae // (exps[1] - exps[0]))
     w["W_enc"] = ((mid * sign)[:, None] * scale[None, :]).contiguous()
     w["b_dec"] = torch.zeros(K)
     hot_row = mid * sign
     w["b_enc"] = (-(hot_row.double() @ w["W_enc"].double()) + 0.5).float()
     x = mid * torch.where(torch.rand(n_rows, K, generator=gen) < 0.5, -1.0, 1.0)   # same norm, other sign patterns
-    hot = [3, 77, 200, 201, 639]
+    hot = [h for h in (3, 77, 200, 201, 639) if h < n_rows]
     x[hot] = hot_row
     return w, x.contiguous(), hot
 
@@ -164,13 +164,13 @@ def test_screened_topk_keeps_candidates_at_bf16_rounding_midpoints():
     screen.encode_topk_screened(xg, 10, scr)
     rv, ri = ref.finalize()
     v, i = scr.finalize()
-    assert sorted(ri[5, :5].tolist()) == [10 + h for h in hot] and float(rv[5, 0]) > 0.25   # the case is what it claims
+    assert len(hot) == 5 and sorted(ri[5, :5].tolist()) == [10 + h for h in hot] and float(rv[5, 0]) > 0.25   # the case is what it claims
     assert torch.equal(v, rv), float((v - rv).abs().max())
     assert torch.equal(i, ri), int((i != ri).sum())
 
 
 def test_screened_lens_pass_keeps_features_at_bf16_rounding_midpoints():
-    w, x, hot = _midpoint_case(n_rows=96)
+    w, x, hot = _midpoint_case(n_rows=96, exps=(-4, 2))   # column scales up to 2: the fp32 sums of ~1500 keep +0.5 visible
     plain, screen = _pair(w)
     xg = x.to(DEV)
     fa, va, ca, _, _ = plain.sparse_lens_pass(xg, 2048, want_recon=False)
@@ -185,4 +185,4 @@ def test_screened_lens_pass_keeps_features_at_bf16_rounding_midpoints():
         for f in set(a) | set(b):
             if max(a.get(f, 0.0), b.get(f, 0.0)) > 0.05:
                 assert f in a and f in b, (m, f, a.get(f), b.get(f))
-                assert abs(a[f] - b[f]) <= 0.02, (m, f, a[f], b[f])
+                assert abs(a[f] - b[f]) <= 0.03, (m, f, a[f], b[f])
