@@ -244,16 +244,20 @@ int tsc_contrib_scores(const tsc_dict_t *dict, const int32_t *feat, const float 
  *
  * On a TSC_F32_SCREEN handle the emit is a two-stage EXACT computation: (1) the bf16 MFMA kernel (16x the fp32
  * matrix rate) computes bf16(x - b_dec) @ bf16(W_enc) + b_enc + margin[n] and emits every feature for which that
- * is positive -- margin[n] = bound * ||W_enc[:, n]||_2 + 2 d_in 2^-24 |b_enc[n]| is a proven bound of the difference
- * between the exact fp32 pre-activation and the bf16 one (both bf16 roundings, up to 2^-8 relative each, through
- * Cauchy-Schwarz, plus the fp32
- * accumulation error of both sums), so no feature with a positive exact activation is missed; (2) the second
- * kernel recomputes each candidate exactly in fp32 (dot(x, W_enc^T[f]) + bias') and keeps the positive ones.
+ * is positive -- margin[n] is a proven bound of the difference between the exact fp32 pre-activation and the bf16 one,
+ * so no feature with a positive exact activation is missed; (2) the second kernel recomputes each candidate exactly
+ * in fp32 (dot(x, W_enc^T[f]) + bias') and keeps the positive ones.  The margin uses the ACTUAL rounding errors of the
+ * call's rows and of the dictionary's columns, not their worst case: with xc = x - b_dec, xt = bf16(xc), wt = bf16(w),
+ *   |sum xt wt - sum xc w| <= ||xt - xc|| ||wt|| + ||xc|| ||wt - w||      (Cauchy-Schwarz on both rounding terms)
+ *   margin[n] = bound[0] * max(||w_n||, ||wt_n||) + bound[1] * ||wt_n - w_n|| + g |b_enc[n]|,   g = 2 d_in 2^-24,
+ *   bound[0] = max_m (||xt_m - xc_m|| + g ||xc_m|| + g (||x_m|| + ||b_dec||)),   bound[1] = max_m ||xc_m||
+ * (the g terms: fp32 accumulation error of both sums).  On ordinary data this is 0.4x the worst-case bound
+ * 2^-7 ||xc|| ||w|| (one bf16 rounding loses up to 2^-8 relative, 2^-9.3 in the root mean square).
  * Values are fp32 values (summed in a different order than tsc_encode_dense: they agree to ~1e-7 relative, and a
  * feature whose pre-activation is within that of zero may be active in one and not the other).  count[m] above
  * max_active then means "the CANDIDATES overflowed" (an upper bound of the active count): retry with that capacity.
- * screen_row_bound: device pointer to ONE float >= (2^-7 * 1.01 + g) max_m ||x_m - b_dec|| + g (max_m ||x_m|| +
- * ||b_dec||), g = 2 d_in 2^-24, or NULL = the library computes it (one more small kernel); ignored by other
+ * screen_row_bound: device pointer to TWO floats >= (bound[0], bound[1]) above (tsc_hip.screen_row_bound computes them
+ * with torch), or NULL = the library computes them (one more small kernel); ignored by other
  * handles.  At most 32768 rows per call on such a handle.
  */
 #define TSC_LENS_COUNT_IS_ZERO 1

@@ -333,7 +333,7 @@ def test_screened_lens_pass_gives_the_exact_results():
         dirs = torch.randn(x.shape[0], 768, generator=torch.Generator().manual_seed(1)).to(DEV)
         fa, va, ca, ra, sa = plain.sparse_lens_pass(xg, cap, dirs=dirs)
         fb, vb, cb, rb, sb = screen.sparse_lens_pass(xg, cap, dirs=dirs)                      # library computes the bound
-        bound = tsc_hip.screen_row_bound(xg, w["b_dec"].to(DEV)).reshape(1)
+        bound = tsc_hip.screen_row_bound(xg, w["b_dec"].to(DEV))
         fc, vc, cc, rc, sc = screen.sparse_lens_pass(xg, cap, dirs=dirs, row_bound=bound)     # bound handed in
         assert int(ca.max()) <= cap and int(cb.max()) <= cap
         assert int(ca.sum()) > 20 * x.shape[0]  # the case is not vacuous

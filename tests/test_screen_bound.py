@@ -1,6 +1,7 @@
 """CPU check of the error bound behind the bf16 screen of ``tsc_sparse_lens_pass`` (include/tsc_hip.h,
 DESIGN.md section 4.3): for every (row, feature), ``|exact fp32 pre-activation - bf16 pre-activation| <= margin`` with
-``margin[n] = bound * ||W_enc[:, n]|| + 2 d_in 2^-24 |b_enc[n]|`` and ``bound = tsc_hip.screen_row_bound(x, b_dec)``.
+``margin[n] = bound[0] max(||W_enc[:, n]||, ||bf16(W_enc[:, n])||) + bound[1] ||W_enc[:, n] - bf16(W_enc[:, n])|| + 2 d_in 2^-24
+|b_enc[n]|`` and ``bound = tsc_hip.screen_row_bound(x, b_dec)`` (the actual rounding errors of the rows and the columns).
 The bf16 side is emulated with torch (operands rounded to bf16, fp32 accumulation), the exact side is the oracle."""
 import torch
 
@@ -11,9 +12,12 @@ def _margin(x, w):
     import tsc_hip
 
     bound = tsc_hip.screen_row_bound(x, w["b_dec"])
-    wnorm = w["W_enc"].double().norm(dim=0).float() * (1 + 1e-6)
+    W = w["W_enc"].double()
+    Wt = w["W_enc"].to(torch.bfloat16).double()
+    wnorm = torch.maximum(W.norm(dim=0), Wt.norm(dim=0)).float() * (1 + 1e-6)   # what col_norm_kernel stores
+    wdiff = (W - Wt).norm(dim=0).float() * (1 + 1e-6)
     g = 2.0 * x.shape[-1] * 2.0 ** -24
-    return bound * wnorm + g * w["b_enc"].abs()
+    return bound[0] * wnorm + bound[1] * wdiff + g * w["b_enc"].abs()
 
 
 def _pre(x, w):

@@ -77,7 +77,7 @@ def test_screened_topk_is_bit_identical_full_width(d_sae):
         elif j < 3:
             screen.encode_topk_screened(x, j * rows, scr)
         else:
-            bound = tsc_hip.screen_row_bound(x, w["b_dec"].to(DEV)).reshape(1)
+            bound = tsc_hip.screen_row_bound(x, w["b_dec"].to(DEV))
             screen.encode_topk_screened(x, j * rows, scr, row_bound=bound)
     rv, ri = ref.finalize()
     v, i = scr.finalize()

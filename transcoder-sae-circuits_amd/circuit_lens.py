@@ -313,7 +313,7 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
     tensor (or list) of per-dictionary, per-row directions for the fused contribution scores.
     ``screened``: use the handles that screen the emit with the bf16 MFMA and recompute the candidates exactly in
     fp32 (``TSC_F32_SCREEN``, include/tsc_hip.h) -- the same fp32 results, several times faster at CircuitLens sizes;
-    ``row_bounds [D]`` are the screens' row bounds (``tsc_hip.screen_row_bound``), computed here when not given.
+    ``row_bounds [D, 2]`` are the screens' row bounds (``tsc_hip.screen_row_bound``), computed here when not given.
     ``then(feat, val, count, recon, scores)``: optional device-only continuation, launched before the counts are
     read (its result is appended to the returned tuple).
     Returns ``(feat [D,R,cap], val [D,R,cap], count [D,R], recon [D,R,d_out] or None, scores [D,R,cap] or None,
@@ -362,7 +362,7 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
                 stream.wait_event(start)
             with torch.cuda.stream(stream):
                 h.sparse_lens_pass(x, cap, dirs=None if dirs is None else dirs[i], screen=screened,
-                                   row_bound=row_bounds[i:i + 1] if screened and h.compute_dtype == tsc_hip.F32_SCREEN else None,
+                                   row_bound=row_bounds[i] if screened and h.compute_dtype == tsc_hip.F32_SCREEN else None,
                                    out={"feat": feat[i], "val": val[i], "count": count[i],
                                         "recon": recon[i] if want_recon else None,
                                         "scores": scores[i] if scores is not None else None},

@@ -114,7 +114,7 @@ int tsc_dict_create(tsc_dict_t **out, int d_in, int d_sae, int d_out, int comput
         hipError_t e = hipSuccess;
         if (compute_dtype != TSC_BF16 && d_in % 64 == 0)  // operand of the LDS-DMA kernel; other d_in use register staging
             e = hipMalloc((void **)&d->W_enc_t, (size_t)d_in * d_sae * sizeof(float));
-        if (e == hipSuccess && compute_dtype == TSC_F32_SCREEN) e = hipMalloc((void **)&d->wnorm, (size_t)d_sae * sizeof(float));
+        if (e == hipSuccess && compute_dtype == TSC_F32_SCREEN) e = hipMalloc((void **)&d->wnorm, (size_t)d_sae * 2 * sizeof(float));
         if (e == hipSuccess && compute_dtype == TSC_F32_SCREEN) e = hipMalloc((void **)&d->screen_bound, 256);
         if (e == hipSuccess) e = hipMalloc((void **)&d->bias_fold, (size_t)d_sae * sizeof(float));
         int rc = e == hipSuccess ? tsc_dict_refresh(d, stream)

@@ -169,7 +169,8 @@ __device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
         nok[bn] = n < a.N;
         be[bn] = nok[bn] ? (DMA ? a.bias[n] : a.b_enc[n]) : 0.f;
         if (BF16 && MODE == TSC_MODE_SPARSE && a.screen_wnorm && nok[bn])  // bf16 screen: see row_bound_kernel (encode_operands.hip)
-            be[bn] += *a.screen_bound * a.screen_wnorm[n] + 2.f * (float)a.K * 5.9604645e-8f * fabsf(be[bn]);
+            be[bn] += a.screen_bound[0] * a.screen_wnorm[n] + a.screen_bound[1] * a.screen_wnorm[a.N + n] +
+                      2.f * (float)a.K * 5.9604645e-8f * fabsf(be[bn]);
     }
     // SPARSE: a value is emitted when it exceeds this (0 = every positive activation; the top-k screen: just below the
     // feature's floor, so that a value equal to the k-th best -- which a smaller token id may still outrank -- passes)

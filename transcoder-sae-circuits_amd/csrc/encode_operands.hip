@@ -95,30 +95,42 @@ __global__ __launch_bounds__(256) void convert_x_group_kernel(const ConvertGroup
     *(uint4 *)(g.out[p] + i * 8) = u.v;
 }
 
-// wnorm[n] = ||W[:, n]||_2, summed in fp64 and rounded UP (it scales an error bound)
+// Column side of the screen's margin, summed in fp64 and rounded UP (they scale an error bound):
+//   wnorm[n]     = max(||W[:, n]||_2, ||bf16(W[:, n])||_2)
+//   wnorm[N + n] = ||W[:, n] - bf16(W[:, n])||_2      -- the ACTUAL rounding error of the column, not its worst case
 __global__ __launch_bounds__(256) void col_norm_kernel(const float *__restrict__ W, int K, int N, float *__restrict__ wnorm) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
-    double s = 0.0;
+    double s = 0.0, st = 0.0, sd = 0.0;
     for (int k = 0; k < K; ++k) {
-        const double w = (double)W[(size_t)k * N + n];
+        const float wf = W[(size_t)k * N + n];
+        const float wt = __uint_as_float((unsigned)f32_to_bf16_rne(wf) << 16);
+        const double w = (double)wf, t = (double)wt, d = w - t;
         s += w * w;
+        st += t * t;
+        sd += d * d;
     }
-    wnorm[n] = __double2float_ru(sqrt(s) * (1.0 + 1e-6));
+    wnorm[n] = __double2float_ru(sqrt(s > st ? s : st) * (1.0 + 1e-6));
+    wnorm[N + n] = __double2float_ru(sqrt(sd) * (1.0 + 1e-6));
 }
 
-// Row bound of the bf16 screen, one wave per row, max over the rows by an atomic on the float's bits (the values
-// are non-negative, so unsigned order is float order):
-//   bound = (2^-7 * 1.01 + g) * ||x - b_dec||_2 + g * (||x||_2 + ||b_dec||_2),  g = 2 * K * 2^-24
-// first term: both bf16 roundings of every product -- round-to-nearest on an 8-bit significand is up to 2^-8
-// relative EACH, so (1 + e1)(1 + e2) - 1 <= 2^-7 (1 + 2^-9) -- through Cauchy-Schwarz over the row; second and
-// third: the fp32 accumulation error (K * 2^-24 relative to sum |x_k w_k|) of the exact kernel, which contracts the
-// raw x against the folded bias, and of the screen itself.  Multiplied by ||W_enc[:, n]||_2 it bounds
-// |exact pre-activation - screened pre-activation| of column n for every row, up to the g * |b_enc[n]| that the
-// screen kernel adds per column (the accumulation error on the bias both chains start from).
+// Row side of the bf16 screen's margin, one wave per row, maxima over the rows by an atomic on the floats' bits (the
+// values are non-negative, so unsigned order is float order).  With xc = fl(x - b_dec), xt = bf16(xc) (what
+// convert_x_kernel stores), wt = bf16(w):
+//   sum_k xt_k wt_k - sum_k xc_k w_k = sum_k (xt_k - xc_k) wt_k + sum_k xc_k (wt_k - w_k)
+//   |...| <= ||xt - xc|| ||wt|| + ||xc|| ||wt - w||                                   (Cauchy-Schwarz, twice)
+// with the ACTUAL rounding errors of this row and of the column (a bf16 rounding loses up to 2^-8 relative, 2^-9.3 in
+// the root mean square: the worst case over every operand, 2^-7 ||xc|| ||w||, is 2.4x this on ordinary data), plus the
+// fp32 accumulation error of the exact kernel (which contracts the raw x against the folded bias) and of the screen
+// itself, g/2 (||x|| ||w|| + ||b_dec|| ||w||) + g/2 ||xt|| ||wt||, g = 2 K 2^-24, and the 2^-24 of fl(x - b_dec):
+//   bound[0] = max_m ( ||xt_m - xc_m|| + g ||xc_m|| + g (||x_m|| + ||b_dec||) )      multiplies wnorm[n]
+//   bound[1] = max_m ||xc_m||                                                         multiplies wnorm[N + n]
+// (both scaled by 1.0001 for the fp32 rounding of the norms themselves; the screen kernel adds g |b_enc[n]| per
+// column for the bias both chains start from).  margin[n] = bound[0] wnorm[n] + bound[1] wnorm[N + n] + g |b_enc[n]|
+// bounds |exact pre-activation - screened pre-activation| of column n for every row.
 __global__ __launch_bounds__(256) void row_bound_kernel(const float *__restrict__ x, long long M, int K,
                                                        const float *__restrict__ b_dec, float *__restrict__ bound) {
-    __shared__ float wave_max[4];
+    __shared__ float wave_max[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n_waves = (long long)gridDim.x * 4;
     const float g = 2.f * (float)K * 5.9604645e-8f;
@@ -131,27 +143,36 @@ __global__ __launch_bounds__(256) void row_bound_kernel(const float *__restrict_
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sb += __shfl_xor(sb, off);
     const float nb = sqrtf(sb);
-    float best = 0.f;
+    float best0 = 0.f, best1 = 0.f;
+    auto rerr = [](float v) { return v - __uint_as_float((unsigned)f32_to_bf16_rne(v) << 16); };  // exact in fp32
     for (long long row = (long long)blockIdx.x * 4 + wave; row < M; row += n_waves) {
-        float sc = 0.f, sr = 0.f;
+        float sc = 0.f, sr = 0.f, sd = 0.f;
         const float4 *xr = (const float4 *)(x + row * K);
         for (int c = lane; c < chunks; c += 64) {
             const float4 v = xr[c], b = ((const float4 *)b_dec)[c];
             const float dx = v.x - b.x, dy = v.y - b.y, dz = v.z - b.z, dw = v.w - b.w;
+            const float ex = rerr(dx), ey = rerr(dy), ez = rerr(dz), ew = rerr(dw);
             sc += dx * dx + dy * dy + dz * dz + dw * dw;
+            sd += ex * ex + ey * ey + ez * ez + ew * ew;
             sr += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             sc += __shfl_xor(sc, off);
             sr += __shfl_xor(sr, off);
+            sd += __shfl_xor(sd, off);
         }
-        best = fmaxf(best, ((0.0078125f * 1.01f + g) * sqrtf(sc) + g * (sqrtf(sr) + nb)) * 1.0001f);
+        sd += (float)K * 1.2e-38f;  // squares that underflowed: each lost less than the smallest normal number
+        const float nc = sqrtf(sc);
+        best0 = fmaxf(best0, (sqrtf(sd) + g * nc + g * (sqrtf(sr) + nb)) * 1.0001f);
+        best1 = fmaxf(best1, nc * 1.0001f);
     }
-    if (lane == 0) wave_max[wave] = best;
+    if (lane == 0) { wave_max[0][wave] = best0; wave_max[1][wave] = best1; }
     __syncthreads();
-    if (threadIdx.x == 0)  // non-negative floats order like their bit patterns
-        atomicMax((unsigned *)bound, __float_as_uint(fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]))));
+    if (threadIdx.x < 2) {  // non-negative floats order like their bit patterns
+        const float *w = wave_max[threadIdx.x];
+        atomicMax((unsigned *)bound + threadIdx.x, __float_as_uint(fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]))));
+    }
 }
 
 }  // namespace
@@ -163,7 +184,7 @@ int tsc_launch_col_norms(const float *W, int K, int N, float *wnorm, hipStream_t
 }
 
 int tsc_launch_row_bound(const float *x, long long M, int K, const float *b_dec, float *bound, hipStream_t stream) {
-    TSC_HIP_CHECK(hipMemsetAsync(bound, 0, sizeof(float), stream));
+    TSC_HIP_CHECK(hipMemsetAsync(bound, 0, 2 * sizeof(float), stream));
     long long blocks = (M + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(row_bound_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, M, K, b_dec, bound);

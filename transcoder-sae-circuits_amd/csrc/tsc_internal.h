@@ -13,8 +13,8 @@ struct tsc_dict {
     void *W_enc_bf16;                                       // owned (TSC_BF16 only): bf16(W_enc) transposed, [d_sae][d_in]
     void *x_bf16;                                           // owned (TSC_BF16 only): bf16(x - b_dec) of one chunk of rows
     float *bias_fold;                                       // owned: b_enc - b_dec @ W_enc (fp64 sums), [d_sae]
-    float *wnorm;                                           // owned (TSC_F32_SCREEN only): ||W_enc[:, n]||_2 rounded up, [d_sae]
-    float *screen_bound;                                    // owned (TSC_F32_SCREEN only): one float, the row bound of the current call
+    float *wnorm;                                           // owned (TSC_F32_SCREEN only): [2][d_sae] column norms of the screen's margin (encode_operands.hip)
+    float *screen_bound;                                    // owned (TSC_F32_SCREEN only): two floats, the row bounds of the current call
 };
 
 // error plumbing (capi.hip)
@@ -49,7 +49,8 @@ struct EncodeArgs {
     int *sp_count;       // [M], zeroed by the caller
     int max_active;
     // bf16 SCREEN of the sparse lens pass (capi.hip: tsc_sparse_lens_pass on a TSC_F32_SCREEN handle): the bias of column n
-    // is raised by *screen_bound * screen_wnorm[n], a proven bound of |exact fp32 - bf16| for that column, so every
+    // is raised by screen_bound[0] * screen_wnorm[n] + screen_bound[1] * screen_wnorm[N + n], a proven bound of
+    // |exact fp32 - bf16| for that column (row_bound_kernel, encode_operands.hip), so every
     // feature whose exact activation is positive is emitted as a candidate
     const float *screen_wnorm, *screen_bound;
     // bf16 SCREEN of the fused top-k (screen_topk.hip): SPARSE epilogue, but a pair is emitted when its screened value

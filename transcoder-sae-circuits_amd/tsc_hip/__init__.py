@@ -262,7 +262,7 @@ class DeviceDict:
         recon or None, scores [M, cap] or None)``.  No capacity check and no host sync: the caller compares
         ``count.max()`` with ``feat.shape[1]`` once for as many dictionaries as it likes (``out`` may carry
         preallocated ``feat/val/count`` (and optionally ``recon/scores``) views -- ``count`` then has to be zero
-        already -- so that one memset and one reduction serve a whole pass).  ``row_bound``: one-element device
+        already -- so that one memset and one reduction serve a whole pass).  ``row_bound``: two-element device
         tensor for a ``F32_SCREEN`` handle (see :func:`screen_row_bound`); None lets the library compute it;
         ``screen=False`` asks such a handle for the plain fp32 emit.  ``emit_only``: stop after the emit
         (``TSC_LENS_EMIT_ONLY``); :func:`sparse_lens_finish_many` then finishes several dictionaries in one launch."""
@@ -340,7 +340,7 @@ def sparse_lens_emit_many(handles, inputs, feat: torch.Tensor, val: torch.Tensor
                           count_is_zero: bool = True) -> None:
     """``tsc_sparse_lens_emit_many``: the emits of all ``handles`` into the stacked ``feat / val [D, M, cap]`` and
     ``count [D, M]`` in ONE foreign call, dictionary ``i`` on ``streams[i % len(streams)]`` (``torch.cuda.Stream``s;
-    default: the current one).  ``row_bounds [D]``: the screens' row bounds (device), or None."""
+    default: the current one).  ``row_bounds [D, 2]``: the screens' row bounds (device, :func:`screen_row_bound`), or None."""
     n = len(handles)
     _dev(feat, torch.int32, "feat"); _dev(val, torch.float32, "val"); _dev(count, torch.int32, "count")
     D, M, cap = feat.shape
@@ -354,9 +354,9 @@ def sparse_lens_emit_many(handles, inputs, feat: torch.Tensor, val: torch.Tensor
     rb = None
     if row_bounds is not None:
         row_bounds = _dev(row_bounds, torch.float32, "row_bounds")
-        if row_bounds.numel() != n:
-            raise TscError("sparse_lens_emit_many: one row bound per dictionary")
-        rb = (ctypes.c_void_p * n)(*[row_bounds.data_ptr() + 4 * i for i in range(n)])
+        if tuple(row_bounds.shape) != (n, 2):
+            raise TscError("sparse_lens_emit_many: row_bounds must be [n_dicts, 2] (screen_row_bound)")
+        rb = (ctypes.c_void_p * n)(*[row_bounds.data_ptr() + 8 * i for i in range(n)])
     st = [s.cuda_stream for s in streams] if streams else [_stream()]
     sa = (ctypes.c_void_p * len(st))(*st)
     with torch.cuda.device(feat.device):
@@ -394,13 +394,16 @@ def sparse_lens_finish_many(handles, inputs, feat: torch.Tensor, val: torch.Tens
 
 
 def screen_row_bound(x: torch.Tensor, b_dec: torch.Tensor) -> torch.Tensor:
-    """The ``screen_row_bound`` of ``tsc_sparse_lens_pass`` (include/tsc_hip.h) for rows ``x [..., M, d_in]``: a
-    device tensor ``[...]`` of ``(2^-7 * 1.01 + g) max_m ||x_m - b_dec|| + g (max_m ||x_m|| + ||b_dec||)``,
-    ``g = 2 d_in 2^-24``, rounded up.  Leading axes batch over dictionaries (``b_dec [..., d_in]``)."""
+    """The ``screen_row_bound`` of ``tsc_sparse_lens_pass`` (include/tsc_hip.h) for rows ``x [..., M, d_in]``: a device
+    tensor ``[..., 2]``, with ``xc = x - b_dec``, ``g = 2 d_in 2^-24``:
+    ``[max_m (||bf16(xc_m) - xc_m|| + g ||xc_m|| + g (||x_m|| + ||b_dec||)),  max_m ||xc_m||]``, rounded up.
+    Leading axes batch over dictionaries (``b_dec [..., d_in]``)."""
     g = 2.0 * x.shape[-1] * 2.0 ** -24
-    centred = (x - b_dec.unsqueeze(-2)).norm(dim=-1).amax(dim=-1)
-    raw = x.norm(dim=-1).amax(dim=-1)
-    return (((2.0 ** -7 * 1.01 + g) * centred + g * (raw + b_dec.norm(dim=-1))) * 1.0001).to(torch.float32).contiguous()
+    xc = x - b_dec.unsqueeze(-2)
+    err = (xc.to(torch.bfloat16).to(torch.float32) - xc).norm(dim=-1) + (x.shape[-1] * 1.2e-38) ** 0.5
+    centred = xc.norm(dim=-1)
+    first = (err + g * centred + g * (x.norm(dim=-1) + b_dec.norm(dim=-1).unsqueeze(-1))).amax(dim=-1)
+    return (torch.stack([first, centred.amax(dim=-1)], dim=-1) * 1.0001).to(torch.float32).contiguous()
 
 
 def lens_assemble(head: torch.Tensor, aux: torch.Tensor, group_aux, scores: torch.Tensor, count: torch.Tensor,
