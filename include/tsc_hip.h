@@ -324,6 +324,22 @@ int tsc_lens_assemble(int64_t R, int n_head, int n_groups, const int32_t *group_
                       int32_t *top_info, tsc_stream_t stream);
 
 /*
+ * Many row-wise dot products in one launch:
+ *   out[j][r * out_stride[j]] = sum_k (a[j][r * a_stride[j] + k] - c[j][r * c_stride[j] + k]) * b[j][r * b_stride[j] + k],  k < d,
+ * for n_terms terms and R rows; an operand stride of 0 means one vector shared by all rows; c (the whole table or single
+ * entries) may be NULL = nothing subtracted.  a, c, b, out and the stride tables are HOST arrays of n_terms entries; the
+ * operands they point at are device memory, 16-byte aligned, strides 0 or >= d and multiples of 4; d % 4 == 0.
+ * Replaces the auxiliary rows of CircuitLens.get_active_features dotted with a lens direction -- embed, pos_embed
+ * (circuit_lens.py:570-575), b_O, the z-SAE error and bias through W_O (:591-604), the transcoder error and bias
+ * (:640-645), each against the row's direction as in :762-766 -- for all layers and all positions of a batch at once
+ * (62 terms for GPT-2 small); as separate tensor operations these were 17 launches over [layers, rows, 768] temporaries.
+ * Sums run in a fixed order (lane-strided partial sums, then a 64-lane butterfly): results are reproducible.
+ */
+int tsc_rowdot_many(int n_terms, const float *const *a, const int64_t *a_stride, const float *const *c,
+                    const int64_t *c_stride, const float *const *b, const int64_t *b_stride, float *const *out,
+                    const int64_t *out_stride, int64_t R, int d, tsc_stream_t stream);
+
+/*
  * Scores of a few selected features for every token, without touching the other d_sae - F columns:
  *   out[m, j] = act( dot(x[m,:] - b_dec, Pt[j,:]) + bias[j] ),  act = ReLU if apply_relu else identity,
  * Pt [F, d_in] holds the selected encoder columns as rows (W_enc[:, feats] transposed), bias [F],

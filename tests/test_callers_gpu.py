@@ -130,6 +130,16 @@ def _ids(runs):
     return [[gi.COMPONENT_IDS.index(r.component), r.run_data["layer"], r.run_data["feature"]] for r, _ in runs]
 
 
+def _assert_mismatches_are_near_ties(mismatch_ranks, ref_sorted_values, tol=2 * ATOL):
+    """A rank at which two rankings name different components is tolerated only where the reference's own values
+    make it a near-tie: the value at that rank is within ``tol`` of its neighbour above or below (``ref_sorted_values``
+    reaches one rank past the compared ones, so that the boundary of the top-k counts too)."""
+    v = [float(x) for x in ref_sorted_values]
+    for j in mismatch_ranks:
+        gaps = [abs(v[j] - v[i]) for i in (j - 1, j + 1) if 0 <= i < len(v)]
+        assert gaps and min(gaps) <= tol, (j, v)
+
+
 def test_logit_difference_against_the_reference_class():
     from task_evaluation import TaskEvaluation
 
@@ -231,8 +241,9 @@ def test_batched_circuit_lens_equals_single_prompt_lenses():
                 ref_runs, _ = view.get_direction_lens(dirs[i], pos, visualize=False, k=10)
                 got_runs = runs_all[row]
                 assert len(got_runs) == len(ref_runs)
-                mism = sum(a != b for a, b in zip(_ids(got_runs), _ids(ref_runs)))
-                assert mism <= 2  # near-equal contributions may swap
+                mism = [j for j, (a, b) in enumerate(zip(_ids(got_runs), _ids(ref_runs))) if a != b]
+                assert len(mism) <= 2  # near-equal contributions may swap ...
+                _assert_mismatches_are_near_ties(mism, ref.sort(descending=True).values[:len(ref_runs) + 1])  # ... and only those
                 _close(torch.tensor([v for _, v in got_runs]), torch.tensor([v for _, v in ref_runs]), atol=ATOL)
             row += 1
     # the evaluation-position form (config 4): one row per prompt, logit-difference directions
@@ -248,10 +259,42 @@ def test_batched_circuit_lens_equals_single_prompt_lenses():
         v, idx = ref.topk(10)
         _close(out["top_values"][i], v, atol=ATOL)
         feats = af.features[idx]
-        same = (out["top_feature"][i] == feats).sum()
-        assert int(same) >= 8
+        differ = (out["top_feature"][i] != feats).nonzero().flatten().tolist()
+        assert len(differ) <= 2
+        _assert_mismatches_are_near_ties(differ, ref.topk(11).values)
     with pytest.raises(ValueError):
         te.batched_lens().lens(0).get_active_features(0)  # position not covered by an eval-position pass
+
+
+def test_batched_lens_revalidates_its_cached_handles():
+    """``BatchedCircuitLens`` reuses the library handles and call tables of its first pass without checking them on
+    the way in (the check runs while the GPU works).  A parameter updated in place, or re-allocated, between two
+    passes must still give the results of a fresh batch: the pass that ran on stale handles is redone."""
+    from circuit_lens import BatchedCircuitLens
+
+    g5, *_, prompts = gi.g5_inputs()
+    _lens_world()
+    texts = [p["text"] for p in prompts[:6]]
+    dirs = torch.randn(len(texts), 768, generator=torch.Generator().manual_seed(9)).to(DEV)
+    batch = BatchedCircuitLens(texts, positions=-1)
+    first = batch.direction_lens(dirs, k=10)
+    again = batch.direction_lens(dirs, k=10)          # cached handles, nothing changed
+    for name in ("top_values", "top_feature", "activations"):
+        assert torch.equal(first[name], again[name]), name
+
+    def fresh():
+        return BatchedCircuitLens(texts, positions=-1).direction_lens(dirs, k=10)
+
+    batch.mlp_transcoders[1].b_enc.add_(0.05)          # in place: same storage, new version -> refresh + rerun
+    got, want = batch.direction_lens(dirs, k=10), fresh()
+    assert not torch.equal(got["activations"], first["activations"])
+    for name in ("top_values", "top_feature", "activations"):
+        assert torch.equal(got[name], want[name]), name
+    z = batch.z_saes[0]                                # re-allocated: a new handle -> rerun
+    z.W_enc = torch.nn.Parameter((z.W_enc.detach() * 1.01).clone())
+    got, want = batch.direction_lens(dirs, k=10), fresh()
+    for name in ("top_values", "top_feature", "activations"):
+        assert torch.equal(got[name], want[name]), name
 
 
 def test_fused_lens_pass_matches_the_separate_kernels():

@@ -305,17 +305,25 @@ def _pass_streams(dev, n: int = 4):
 
 
 def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want_recon: bool = True,
-                        screened: bool = True, row_bounds: Optional[torch.Tensor] = None, then=None):
+                        screened: bool = True, row_bounds: Optional[torch.Tensor] = None, then=None,
+                        handle_cache: Optional[dict] = None):
     """All dictionaries of ``encoders`` (a list) over their ``inputs`` (a list of ``[R, d_in]`` tensors, the
     same R for all) with ONE host synchronisation: the counts of every dictionary live in one tensor that is
     zeroed once, checked against the capacity once and copied to the host once, and the outputs of all
     dictionaries are slices of stacked buffers (no per-dictionary allocation).  ``dirs``: optional ``[D, R, d_out]``
-    tensor (or list) of per-dictionary, per-row directions for the fused contribution scores.
+    tensor (or list) of per-dictionary, per-row directions for the fused contribution scores -- or a callable that
+    returns them: it is then called AFTER the emits have been queued (they do not need the directions), so that the
+    device work behind the directions and the host time of preparing them hide under the emit kernel.
     ``screened``: use the handles that screen the emit with the bf16 MFMA and recompute the candidates exactly in
     fp32 (``TSC_F32_SCREEN``, include/tsc_hip.h) -- the same fp32 results, several times faster at CircuitLens sizes;
     ``row_bounds [D, 2]`` are the screens' row bounds (``tsc_hip.screen_row_bound``), computed here when not given.
     ``then(feat, val, count, recon, scores)``: optional device-only continuation, launched before the counts are
     read (its result is appended to the returned tuple).
+    ``handle_cache``: a dict the caller keeps between passes over the SAME encoders and inputs.  With it the library
+    handles (24 look-ups, each checking five parameter addresses and versions) and the marshalled call tables are
+    reused WITHOUT validation on the way in -- the GPU idles until the emit is queued -- and validated while the
+    GPU works: a handle borrows tensors it keeps alive, so a stale one is harmless to launch, and a pass that ran on
+    stale handles (a parameter was re-allocated or updated in place since) is simply run again.
     Returns ``(feat [D,R,cap], val [D,R,cap], count [D,R], recon [D,R,d_out] or None, scores [D,R,cap] or None,
     counts on host [D,R])``."""
     import tsc_hip
@@ -326,10 +334,23 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
     d_out = encoders[0].W_dec.shape[1]
     cap = max(1, min(int(max_active), tsc_hip.LENS_PASS_MAX_ACTIVE))
     screened = screened and rows <= 32768
-    handles = [enc.device_dict(screened=screened) for enc in encoders]
+
+    def look_up():
+        hs = [enc.device_dict(screened=screened) for enc in encoders]
+        return hs, [h._versions for h in hs]
+
+    cached = handle_cache.get(screened) if handle_cache is not None else None
+    unvalidated = cached is not None
+    if cached is None:
+        handles, versions = look_up()
+        cached = {"handles": handles, "versions": versions, "group": None}
+        if handle_cache is not None:
+            handle_cache[screened] = cached
+    handles = cached["handles"]
     if screened and row_bounds is None:
         row_bounds = torch.stack([tsc_hip.screen_row_bound(x, enc.b_dec.detach()) for enc, x in zip(encoders, inputs)])
     tail = None
+    dirs_fn = dirs if callable(dirs) else None
     while True:
         feat = torch.empty(n_d, rows, cap, dtype=torch.int32, device=dev)
         val = torch.empty(n_d, rows, cap, dtype=torch.float32, device=dev)
@@ -341,21 +362,29 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
         # Every buffer was allocated on the calling stream and outlives the pass; the side streams start after the
         # calling stream's work so far and the calling stream waits for all of them before the counts are read.
         main = torch.cuda.current_stream(dev)
-        n_side = int(os.environ.get("TSC_LENS_STREAMS", "4"))  # 1: everything on the current stream (profiling)
-        side = _pass_streams(dev, n_side) if rows <= 8192 and n_d > 1 and n_side > 1 else []
         # ... and, with several dictionaries, stop each after its emit and finish them all in ONE launch
         # (tsc_sparse_lens_finish_many): one dictionary's 512 rows are two workgroups per CU, 24 x 512 fill the chip.
         grouped = 1 < n_d <= 32 and rows <= 8192 and len({(h.compute_dtype, h.d_in, h.d_out) for h in handles}) == 1 and \
             len({id(h) for h in handles}) == n_d and os.environ.get("TSC_LENS_GROUPED", "1") != "0"
+        n_side = int(os.environ.get("TSC_LENS_STREAMS", "4"))  # 1: everything on the current stream (profiling)
+        # (the grouped emit is one launch on the current stream: no side streams, no cross-stream events to queue)
+        one_launch = grouped and screened and handles[0].compute_dtype == tsc_hip.F32_SCREEN
+        side = _pass_streams(dev, n_side) if rows <= 8192 and n_d > 1 and n_side > 1 and not one_launch else []
         _mark("pass: buffers ready")
-        start = torch.cuda.Event()
-        start.record(main)
+        if side:
+            start = torch.cuda.Event()
+            start.record(main)
+        if dirs_fn is not None and not grouped:
+            dirs = dirs_fn()  # the fused per-dictionary calls take their directions with the emit
         if grouped:  # every emit in one foreign call (24 separate calls cost more host time than their kernels run)
             for stream in side:
                 stream.wait_event(start)
-            tsc_hip.sparse_lens_emit_many(handles, inputs, feat, val, count, screen=screened,
-                                          row_bounds=row_bounds if screened and handles[0].compute_dtype == tsc_hip.F32_SCREEN else None,
-                                          streams=side or None)
+            group = cached["group"]
+            if group is None or len(group.inputs) != n_d or any(a is not b for a, b in zip(group.inputs, inputs)):
+                group = cached["group"] = tsc_hip.LensGroup(handles, inputs)
+            group.emit(feat, val, count, screen=screened,
+                       row_bounds=row_bounds if screened and handles[0].compute_dtype == tsc_hip.F32_SCREEN else None,
+                       streams=side or None)
         for i, (h, x) in enumerate(zip(handles, inputs) if not grouped else ()):
             stream = side[i % len(side)] if side else main
             if side and i < len(side):
@@ -371,14 +400,23 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
             main.wait_stream(stream)
         _mark("pass: emits done")
         if grouped:
-            tsc_hip.sparse_lens_finish_many(handles, inputs, feat, val, count, dirs=dirs, recon=recon, scores=scores,
-                                            screen=screened)
+            if dirs_fn is not None:
+                dirs = dirs_fn()
+            group.finish(feat, val, count, dirs=dirs, recon=recon, scores=scores, screen=screened)
         # work that only consumes this pass's device buffers is queued BEFORE the host looks at the counts, so the
         # GPU never drains in the middle of the pass; it is redone in the (rare) retry with a larger capacity
         _mark("pass: finish done")
         if then is not None:
             tail = then(feat, val, count, recon, scores)
         _mark("pass: tail queued")
+        if unvalidated:  # the look-ups that were skipped on the way in, now that the GPU has work
+            unvalidated = False
+            fresh, versions = look_up()
+            # (a refresh -- in-place parameter update -- replaces the handle's version tuple)
+            if any(f is not h for f, h in zip(fresh, handles)) or any(v is not w for v, w in zip(versions, cached["versions"])):
+                cached.update(handles=fresh, versions=versions, group=None)
+                handles = fresh
+                continue  # the pass ran on handles of older parameters: again, with the current ones
         counts_host = count.cpu()  # the one synchronisation of the pass
         _mark("pass: counts on host")
         worst = int(counts_host.max()) if counts_host.numel() else 0
@@ -765,6 +803,7 @@ class BatchedCircuitLens:
         self._row_pos_host = rs
         self._pass = None
         self._views: Dict[int, CircuitLens] = {}
+        self._handle_cache: dict = {}  # run_dictionary_pass: library handles + call tables of this batch's passes
 
     @property
     def n_prompts(self):
@@ -836,7 +875,7 @@ class BatchedCircuitLens:
             dirs, _ = self._dictionary_directions(self._row_directions(directions))
         with torch.no_grad():
             out = run_dictionary_pass(encs, xs, self.max_active, dirs=dirs, screened=self.screened,
-                                      row_bounds=self._row_bounds())
+                                      row_bounds=self._row_bounds(), handle_cache=self._handle_cache)
         if self._pass is None or directions is None:
             self._pass = out
         return out
@@ -897,30 +936,35 @@ class BatchedCircuitLens:
         d = self._row_directions(directions)
         encs, xs = self._encoders_and_inputs()
         with torch.no_grad():
-            dirs, dz = self._dictionary_directions(d)
             t = self._tables()
-            _mark("lens: directions ready")
             n_layers, rows = self.model.cfg.n_layers, self.n_rows
+            state = {}
+
+            def dirs_after_emit():
+                # queued behind the emits, which do not need them: the pull-back through W_O and its host time are hidden
+                state["dirs"], state["dz"] = self._dictionary_directions(d)
+                _mark("lens: directions queued")
+                return state["dirs"]
 
             def tail(feat, val, count, recon, scores):
                 # (everything here is queued behind the dictionaries' launches: the host works while the GPU does)
-                head = torch.stack([(t["embed"] * d).sum(-1), (t["pos_embed"] * d).sum(-1)], dim=1).contiguous()
-                b_o = d @ t["b_o"].t()                                                    # [R, L]
-                z_bias = (t["z_b_dec"][:, None, :] * dz).sum(-1).t()
-                t_bias = d @ t["t_b_out"].t()
-                # auxiliary rows of every layer at once (row order of ActiveFeatures: b_O, z error, z bias | error, bias)
-                z_err = ((t["z"] - recon[0::2]) * dz).sum(-1).t()
-                t_err = ((t["mlp_out"] - recon[1::2]) * d[None]).sum(-1).t()
-                aux = torch.stack([b_o, z_err, z_bias, t_err, t_bias], dim=2).reshape(rows, -1).contiguous()  # [R, 5L]
-                return tsc_hip.lens_assemble(head, aux, [3, 2] * n_layers, scores, count, k=k, dense=dense,
-                                             column_tags=self._column_tags(d.device), feat=feat)
+                # head = embed, pos_embed; auxiliary rows of every layer (row order of ActiveFeatures: b_O, z error,
+                # z bias | transcoder error, transcoder bias), each dotted with the row's direction: ONE launch
+                head = torch.empty(rows, 2, dtype=torch.float32, device=d.device)
+                aux = torch.empty(rows, 5 * n_layers, dtype=torch.float32, device=d.device)
+                self._aux_dots(d, state["dz"], recon, head, aux)
+                res = tsc_hip.lens_assemble(head, aux, [3, 2] * n_layers, scores, count, k=k, dense=dense,
+                                            column_tags=self._column_tags(d.device), feat=feat)
+                res["top_info_long"] = res["top_info"].long()  # (queued here: nothing is launched after the host sync)
+                return res
 
             feat, val, count, recon, scores, counts_host, res = run_dictionary_pass(
-                encs, xs, self.max_active, dirs=dirs, screened=self.screened, row_bounds=self._row_bounds(), then=tail)
+                encs, xs, self.max_active, dirs=dirs_after_emit, screened=self.screened, row_bounds=self._row_bounds(),
+                then=tail, handle_cache=self._handle_cache)
             if self._pass is None:
                 self._pass = (feat, val, count, recon, scores, counts_host)
             _mark("lens: pass returned")
-            info = res["top_info"].long()  # [R, k, 4]: column, component, layer, feature (-1 where a row ran out)
+            info = res["top_info_long"]  # [R, k, 4]: column, component, layer, feature (-1 where a row ran out)
             out = {
                 "top_values": res["top_values"],
                 "top_component": info[:, :, 1], "top_layer": info[:, :, 2], "top_feature": info[:, :, 3],
@@ -930,6 +974,44 @@ class BatchedCircuitLens:
             if dense:
                 out.update(activations=res["activations"], mask=res["mask"], raw=res["raw"])
             return out
+
+    def _aux_dots(self, d, dz, recon, head, aux) -> None:
+        """``head [R, 2]`` / ``aux [R, 5 L]`` = the non-feature rows of every position's ``ActiveFeatures`` dotted with
+        the row's direction (``tsc_rowdot_many``, one launch).  The term table is built once per batch; a pass only
+        patches the addresses of what it allocated (directions, reconstructions, outputs)."""
+        import tsc_hip
+
+        t = self._tables()
+        n_layers, rows, dm = self.model.cfg.n_layers, self.n_rows, d.shape[1]
+        tab = getattr(self, "_rd", None)
+        if tab is None:
+            tab = tsc_hip.RowDotTable(2 + 5 * n_layers, rows, dm)
+            tab.set(0, t["embed"], None, d, head[:, 0])
+            tab.set(1, t["pos_embed"], None, d, head[:, 1])
+            for l in range(n_layers):
+                j = 2 + 5 * l
+                tab.set(j, t["b_o"][l], None, d, aux[:, 5 * l])
+                tab.set(j + 1, t["z"][l], recon[2 * l], dz[l], aux[:, 5 * l + 1])
+                tab.set(j + 2, t["z_b_dec"][l], None, dz[l], aux[:, 5 * l + 2])
+                tab.set(j + 3, t["mlp_out"][l], recon[2 * l + 1], d, aux[:, 5 * l + 3])
+                tab.set(j + 4, t["t_b_out"][l], None, d, aux[:, 5 * l + 4])
+            self._rd = tab
+        else:  # same shapes and strides as when the table was made: only base addresses move
+            if not (d.is_contiguous() and dz.is_contiguous() and recon.is_contiguous()) or dz.shape[2] != dm:
+                raise tsc_hip.TscError("direction lens: directions / reconstructions must be contiguous")
+            dp, zp, rp, hp, ap = d.data_ptr(), dz.data_ptr(), recon.data_ptr(), head.data_ptr(), aux.data_ptr()
+            zl, rl = dz.stride(0) * 4, recon.stride(0) * 4
+            b, c, out = tab.b, tab.c, tab.out
+            b[0] = b[1] = dp
+            out[0], out[1] = hp, hp + 4
+            for l in range(n_layers):
+                j = 2 + 5 * l
+                b[j] = b[j + 3] = b[j + 4] = dp
+                b[j + 1] = b[j + 2] = zp + l * zl
+                c[j + 1], c[j + 3] = rp + 2 * l * rl, rp + (2 * l + 1) * rl
+                o = ap + 20 * l
+                out[j], out[j + 1], out[j + 2], out[j + 3], out[j + 4] = o, o + 4, o + 8, o + 12, o + 16
+        tab.run(d.device)
 
     def _column_tags(self, dev):
         """``component << 16 | layer`` for every column class of the padded layout, in ``tsc_lens_assemble``'s order:

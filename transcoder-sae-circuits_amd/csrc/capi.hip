@@ -462,6 +462,27 @@ int tsc_lens_assemble(int64_t R, int n_head, int n_groups, const int32_t *group_
                                     feat, k, raw, acts, mask, top_values, top_info, (hipStream_t)stream);
 }
 
+int tsc_rowdot_many(int n_terms, const float *const *a, const int64_t *a_stride, const float *const *c,
+                    const int64_t *c_stride, const float *const *b, const int64_t *b_stride, float *const *out,
+                    const int64_t *out_stride, int64_t R, int d, tsc_stream_t stream) {
+    if (n_terms < 0 || R < 0) return tsc_fail(TSC_ERR_ARG, "negative count");
+    if (n_terms == 0 || R == 0) return TSC_OK;
+    if (d <= 0 || (d & 3)) return tsc_fail(TSC_ERR_UNSUPPORTED, "rowdot: d %d must be a positive multiple of 4", d);
+    if (!a || !a_stride || !b || !b_stride || !out || !out_stride || (c && !c_stride))
+        return tsc_fail(TSC_ERR_ARG, "null rowdot table");
+    for (int j = 0; j < n_terms; ++j) {
+        if (!a[j] || !b[j] || !out[j] || !aligned16(a[j]) || !aligned16(b[j]) || (c && !aligned16(c[j])))
+            return tsc_fail(TSC_ERR_ARG, "rowdot term %d: null or misaligned operand", j);
+        const int64_t s[4] = {a_stride[j], b_stride[j], c && c[j] ? c_stride[j] : 0, out_stride[j]};
+        for (int q = 0; q < 3; ++q)
+            if (s[q] != 0 && (s[q] < d || (s[q] & 3) || s[q] > 0x7fffffff))
+                return tsc_fail(TSC_ERR_ARG, "rowdot term %d: operand row stride must be 0 or >= d, a multiple of 4", j);
+        if (s[3] < 1 || s[3] > 0x7fffffff) return tsc_fail(TSC_ERR_ARG, "rowdot term %d: output stride must be >= 1", j);
+    }
+    return tsc_launch_rowdot_many(n_terms, a, (const long long *)a_stride, c, (const long long *)c_stride, b,
+                                  (const long long *)b_stride, out, (const long long *)out_stride, R, d, (hipStream_t)stream);
+}
+
 int tsc_decode_rows(const tsc_dict_t *d, const int32_t *feat, const float *val, int64_t n, float *rows,
                     tsc_stream_t stream) {
     int rc = check_decoder(d);

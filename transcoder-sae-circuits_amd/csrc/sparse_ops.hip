@@ -661,6 +661,53 @@ __global__ __launch_bounds__(256) void lens_assemble_kernel(const AssembleArgs p
     }
 }
 
+// Many row-wise dot products in one launch: out_j[r] = sum_k (a_j[r][k] - c_j[r][k]) * b_j[r][k] for every term j and
+// row r, each operand either per row (stride >= d) or one shared vector (stride 0), c optional.  This is the whole
+// auxiliary part of the CircuitLens direction lens -- embed, pos_embed, b_O, z error, z bias, transcoder error and
+// transcoder bias of every layer against the row's direction (reference src/circuit_lens.py:570-575, 591-604, 640-645
+// dotted as in :762-766) -- which as torch ops is 17 launches over [L, R, 768] temporaries.  grid = rows, one
+// workgroup of four waves per row; wave w takes terms w, w + 4, ...; a lane holds three float4 per operand (d = 768).
+constexpr int RD_MAX_TERMS = 64;
+struct RowDotArgs {
+    struct Term {
+        const float *a, *c, *b;
+        float *out;
+        int sa, sc, sb, so;  // element strides between rows (0: shared)
+    } t[RD_MAX_TERMS];
+    long long R;
+    int d, n;
+};
+__global__ __launch_bounds__(256) void rowdot_kernel(const RowDotArgs p) {
+    const long long r = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunks = p.d >> 2;
+    for (int j = wave; j < p.n; j += 4) {  // j is wave-uniform: the term's fields are scalar loads
+        const RowDotArgs::Term &t = p.t[j];
+        const f32x4 *a = (const f32x4 *)(t.a + r * t.sa), *b = (const f32x4 *)(t.b + r * t.sb);
+        const f32x4 *c = t.c ? (const f32x4 *)(t.c + r * t.sc) : nullptr;
+        float part = 0.f;
+        for (int ch0 = 0; ch0 < chunks; ch0 += 64 * 3) {
+            f32x4 av[3], bv[3], cv[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int ch = ch0 + lane + 64 * u;
+                const bool ok = ch < chunks;
+                av[u] = ok ? a[ch] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                bv[u] = ok ? b[ch] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                cv[u] = (ok && c) ? c[ch] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const f32x4 e = av[u] - cv[u];
+                part += e.x * bv[u].x + e.y * bv[u].y + e.z * bv[u].z + e.w * bv[u].w;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if (lane == 0) t.out[r * t.so] = part;
+    }
+}
+
 // one wavefront per token row: the row (minus b_dec) is held in registers, each selected encoder
 // column (a contiguous row of Pt, L2-resident) is dotted against it
 __global__ __launch_bounds__(256) void project_kernel(const float *x, long long M, int d_in, const float *b_dec,
@@ -844,6 +891,25 @@ int tsc_launch_lens_assemble(long long R, int n_head, int n_groups, const int *g
     const size_t lds = p.W <= p.lds_cols ? (size_t)p.W * sizeof(float) : 16;
     hipLaunchKernelGGL(lens_assemble_kernel, dim3((unsigned)R), dim3(256), lds, stream, p);
     TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
+int tsc_launch_rowdot_many(int n, const float *const *a, const long long *sa, const float *const *c, const long long *sc,
+                           const float *const *b, const long long *sb, float *const *out, const long long *so,
+                           long long R, int d, hipStream_t stream) {
+    if (R <= 0 || n <= 0) return TSC_OK;
+    for (int j0 = 0; j0 < n; j0 += RD_MAX_TERMS) {
+        RowDotArgs p;
+        memset(&p, 0, sizeof(p));
+        p.R = R; p.d = d; p.n = n - j0 < RD_MAX_TERMS ? n - j0 : RD_MAX_TERMS;
+        for (int j = 0; j < p.n; ++j) {
+            RowDotArgs::Term &t = p.t[j];
+            t.a = a[j0 + j]; t.b = b[j0 + j]; t.c = c ? c[j0 + j] : nullptr; t.out = out[j0 + j];
+            t.sa = (int)sa[j0 + j]; t.sb = (int)sb[j0 + j]; t.sc = c && sc ? (int)sc[j0 + j] : 0; t.so = (int)so[j0 + j];
+        }
+        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)R), dim3(256), 0, stream, p);
+        TSC_HIP_CHECK(hipGetLastError());
+    }
     return TSC_OK;
 }
 

@@ -121,5 +121,8 @@ int tsc_launch_sparse_finish(const float *W_dec, const float *bias, int d_out, i
                              long long M, int max_active, const float *dirs, long long dir_stride, float *recon,
                              float *scores, const float *x, const float *W_enc_t, const float *bias_fold, int d_in,
                              hipStream_t stream);
+int tsc_launch_rowdot_many(int n, const float *const *a, const long long *sa, const float *const *c, const long long *sc,
+                           const float *const *b, const long long *sb, float *const *out, const long long *so,
+                           long long R, int d, hipStream_t stream);
 int tsc_launch_project(const float *x, long long M, int d_in, const float *b_dec, const float *Pt,
                        const float *bias, int F, int relu, float *out, hipStream_t stream);

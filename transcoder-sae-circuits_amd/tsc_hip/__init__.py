@@ -63,6 +63,8 @@ _SIGNATURES = {
     "tsc_lens_assemble": (_c.c_int, [_c.c_int64, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
                                      _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
                                      _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "tsc_rowdot_many": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                   _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p]),
     "tsc_project_features": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                         _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
 }
@@ -393,6 +395,64 @@ def sparse_lens_finish_many(handles, inputs, feat: torch.Tensor, val: torch.Tens
                                                  scores.data_ptr() if scores is not None else None, _stream()))
 
 
+class LensGroup:
+    """The dictionaries of a CircuitLens pass with their inputs, marshalled ONCE for the two grouped calls
+    (:func:`sparse_lens_emit_many`, :func:`sparse_lens_finish_many`): a caller that runs pass after pass over the same
+    batch (one per direction set) pays the 24-entry ctypes tables once, not per call -- the emit call sits on the
+    pass's critical path, with the GPU idle until it is queued."""
+
+    def __init__(self, handles, inputs):
+        self.handles, self.inputs = list(handles), list(inputs)
+        n = len(self.handles)
+        if n < 1 or len(self.inputs) != n:
+            raise TscError("LensGroup: one input per dictionary")
+        self.rows = int(self.inputs[0].shape[0])
+        for x, h in zip(self.inputs, self.handles):
+            _dev(x, torch.float32, "x")
+            if x.dim() != 2 or x.shape[0] != self.rows or x.shape[1] != h.d_in:
+                raise TscError(f"LensGroup: every input must be [{self.rows}, d_in] (got {tuple(x.shape)})")
+        self.hs = (ctypes.c_void_p * n)(*[h._handle for h in self.handles])
+        self.xs = (ctypes.c_void_p * n)(*[x.data_ptr() for x in self.inputs])
+        self.d_out = self.handles[0].d_out
+        self.device = self.inputs[0].device
+
+    def emit(self, feat, val, count, screen=True, row_bounds=None, streams=None, count_is_zero=True) -> None:
+        n = len(self.handles)
+        D, M, cap = feat.shape
+        if D != n or M != self.rows or tuple(count.shape) != (n, M) or tuple(val.shape) != (n, M, cap):
+            raise TscError("LensGroup.emit: stacked buffers do not match the dictionaries")
+        rb = None
+        if row_bounds is not None:
+            if tuple(row_bounds.shape) != (n, 2) or not row_bounds.is_contiguous() or row_bounds.dtype != torch.float32:
+                raise TscError("LensGroup.emit: row_bounds must be a contiguous float32 [n_dicts, 2] (screen_row_bound)")
+            base = row_bounds.data_ptr()
+            if getattr(self, "_rb_base", None) != base:
+                self._rb, self._rb_base = (ctypes.c_void_p * n)(*range(base, base + 8 * n, 8)), base
+            rb = self._rb
+        st = [s.cuda_stream for s in streams] if streams else [_stream()]
+        sa = (ctypes.c_void_p * len(st))(*st)
+        with torch.cuda.device(self.device):
+            _check(lib().tsc_sparse_lens_emit_many(n, self.hs, self.xs, M, cap, feat.data_ptr(), val.data_ptr(),
+                                                   count.data_ptr(), (1 if count_is_zero else 0) | (0 if screen else 2),
+                                                   rb, sa, len(st)))
+
+    def finish(self, feat, val, count, dirs=None, recon=None, scores=None, screen=True) -> None:
+        n = len(self.handles)
+        D, M, cap = feat.shape
+        if D != n or M != self.rows:
+            raise TscError("LensGroup.finish: stacked buffers do not match the dictionaries")
+        ds = None
+        if scores is not None:
+            if dirs is None:
+                raise TscError("scores need directions")
+            ds = (ctypes.c_void_p * n)(*[_dev(d, torch.float32, "dirs").data_ptr() for d in dirs])
+        with torch.cuda.device(self.device):
+            _check(lib().tsc_sparse_lens_finish_many(n, self.hs, self.xs, M, cap, feat.data_ptr(), val.data_ptr(),
+                                                     count.data_ptr(), 0 if screen else 2, ds, self.d_out,
+                                                     recon.data_ptr() if recon is not None else None,
+                                                     scores.data_ptr() if scores is not None else None, _stream()))
+
+
 def screen_row_bound(x: torch.Tensor, b_dec: torch.Tensor) -> torch.Tensor:
     """The ``screen_row_bound`` of ``tsc_sparse_lens_pass`` (include/tsc_hip.h) for rows ``x [..., M, d_in]``: a device
     tensor ``[..., 2]``, with ``xc = x - b_dec``, ``g = 2 d_in 2^-24``:
@@ -450,6 +510,51 @@ def lens_assemble(head: torch.Tensor, aux: torch.Tensor, group_aux, scores: torc
                                        out["top_info"].data_ptr(), _stream()))
     out["top_columns"] = out["top_info"][:, :, 0]
     return out
+
+
+class RowDotTable:
+    """Term table of ``tsc_rowdot_many``, kept as ctypes arrays so that a caller that runs the same set of dot products
+    again and again (the auxiliary rows of every CircuitLens direction pass) only patches the pointers that changed.
+    A term is ``(a, c or None, b, out)``: ``a / c / b`` tensors ``[R, d]`` (per row) or ``[d]`` (shared), ``out`` a 1-D
+    view ``[R]`` (any stride) of the output buffer.  The table keeps NO reference to the tensors: the caller does."""
+
+    def __init__(self, n_terms: int, rows: int, d: int):
+        self.n, self.rows, self.d = int(n_terms), int(rows), int(d)
+        arr, i64 = ctypes.c_void_p * self.n, ctypes.c_int64 * self.n
+        self.a, self.c, self.b, self.out = arr(), arr(), arr(), arr()
+        self.sa, self.sc, self.sb, self.so = i64(), i64(), i64(), i64()
+
+    def _operand(self, t: Optional[torch.Tensor], name: str):
+        if t is None:
+            return None, 0
+        if not t.is_cuda or t.dtype != torch.float32 or t.stride(-1) != 1 or t.shape[-1] != self.d:
+            raise TscError(f"rowdot: {name} must be a float32 GPU tensor [..., {self.d}] with unit inner stride")
+        if t.dim() == 1:
+            return t.data_ptr(), 0
+        if t.dim() != 2 or t.shape[0] != self.rows:
+            raise TscError(f"rowdot: {name} must be [{self.rows}, {self.d}] or [{self.d}] (got {tuple(t.shape)})")
+        return t.data_ptr(), t.stride(0)
+
+    def set(self, j: int, a, c, b, out) -> None:
+        self.a[j], self.sa[j] = self._operand(a, "a")
+        self.c[j], self.sc[j] = self._operand(c, "c")
+        self.b[j], self.sb[j] = self._operand(b, "b")
+        if not out.is_cuda or out.dtype != torch.float32 or out.dim() != 1 or out.shape[0] != self.rows:
+            raise TscError(f"rowdot: out must be a float32 GPU view [{self.rows}]")
+        self.out[j], self.so[j] = out.data_ptr(), max(1, out.stride(0))
+
+    def run(self, device) -> None:
+        with torch.cuda.device(device):
+            _check(lib().tsc_rowdot_many(self.n, self.a, self.sa, self.c, self.sc, self.b, self.sb, self.out, self.so,
+                                         self.rows, self.d, _stream()))
+
+
+def rowdot_many(terms, rows: int, d: int, device) -> None:
+    """One-shot :class:`RowDotTable`: ``terms`` = list of ``(a, c or None, b, out view [rows])``."""
+    tab = RowDotTable(len(terms), rows, d)
+    for j, (a, c, b, out) in enumerate(terms):
+        tab.set(j, a, c, b, out)
+    tab.run(device)
 
 
 class TopkState:
