@@ -830,7 +830,16 @@ __device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
 #undef TSC_MFMA_BALL
 #undef TSC_MFMA
 
+#ifndef TSC_ABL_NOEPI  // diagnosis builds only (no output): what the launch costs without its epilogues
         epilogue(acc, m0);
+#elif defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int bm = 0; bm < WMB; ++bm)
+#pragma unroll
+            for (int bn = 0; bn < WNB; ++bn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[bm][bn][r]));  // every accumulator stays live
+#endif
     }
 #ifdef TSC_STAMPS
     if (MODE == TSC_MODE_TOPK && (tid == 0 || tid == 192)) {
