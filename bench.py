@@ -343,9 +343,12 @@ def config4_side_object(device, n_prompts=512, reps=5):
         agree = float((ref["top_feature"] == out["top_feature"]).float().mean())
         widths = [w for _, _, w in dictionary_widths()]
         flops = sum(2.0 * D_IN * w * rows for w in widths)
-        # algorithmic bytes of the pass: W_enc once in bf16 (the screen), per active feature its encoder row (the exact
-        # recompute) and its decoder row (reconstruction + score), x and the per-row directions and reconstructions
-        by = sum(D_IN * w * 2 for w in widths) + n_active * (2 * D_IN * 4 + 8) + rows * 24 * D_IN * 4 * 3
+        # ALGORITHMIC bytes of the pass, SURVEY.md section 8(d): per position and dictionary n_active x (one W_dec row +
+        # the 8-byte (feature, value) pair) + the direction, and ONE read of the encode weights (fp32, as the reference
+        # holds them).  The implementation's own extra gathers (the exact recompute reads one W_enc^T row per candidate)
+        # are NOT counted: they are served by the L2s and show up in `fabric_bytes_per_pass` only as far as they miss.
+        by = n_active * (D_IN * 4 + 8) + rows * 24 * D_IN * 4 + sum(D_IN * w * 4 for w in widths)
+        oracle_checked = _oracle_check_config4(batch, te, out, dirs)
         return {
             "workload": f"configs[3]: CircuitLens decomposition, {n_prompts} IOI-shaped prompts x eval position x 24 dictionaries, "
                         "per-prompt logit-difference direction, top-10 components per prompt",
@@ -356,8 +359,12 @@ def config4_side_object(device, n_prompts=512, reps=5):
             "emit": "bf16 MFMA screen (proven error margin) + exact fp32 recompute of the candidates (TSC_F32_SCREEN)",
             "roofline": {"bound": "hbm", "achieved": by / t / 1e9, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
                          "frac": by / t / 1e12 / PEAK_HBM_TBS, "algorithmic_bytes_per_pass": by,
-                         "note": "gathers of W_enc^T rows (exact recompute) and W_dec rows of the active features, mostly "
-                                 "served by the Infinity Cache; the bf16 screen adds %.2f TFLOP per pass" % (flops / 1e12)},
+                         "fabric_bytes_per_pass": _config4_fabric_bytes(),
+                         "note": "SURVEY 8(d) bytes: W_dec row gathers of the active features + one fp32 read of the encode "
+                                 "weights.  The pass is NOT HBM-bound at 512 rows: its two large kernels are the bf16 screen "
+                                 "(%.2f TFLOP per pass, latency-bound: profiles/r03_emit_ablation.json) and the exact "
+                                 "recompute + decode gathers, which run at the L2s' bandwidth" % (flops / 1e12)},
+            "oracle_checked": oracle_checked,
             "plain_fp32_emit": {"ms_per_pass": t_plain * 1e3, "value": rows / t_plain,
                                 "roofline": {"bound": "mfma", "achieved": flops / t_plain / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,
                                              "unit": "TFLOP/s", "frac": flops / t_plain / 1e12 / PEAK_F32_MATRIX_TFLOPS}},
@@ -367,6 +374,151 @@ def config4_side_object(device, n_prompts=512, reps=5):
     finally:
         torch.set_grad_enabled(prev)
         lme.clear_cache()
+
+
+def _config4_fabric_bytes():
+    """Fabric-side bytes of one pass from the tracked PMC summary (per-launch FETCH_SIZE x 2 + WRITE_SIZE of the pass's
+    kernels at 512 rows, summed over the 22 + 2 dictionaries), or None."""
+    path = os.path.join(REPO, "profiles", "r02_config4_fabric_bytes.json")
+    try:
+        k = json.load(open(path))["kernels"]
+        tot = lambda name: k[name]["fetch_bytes_per_launch"] + k[name]["write_bytes_per_launch"]  # noqa: E731
+        return {"bytes": 22 * tot("emit bf16 screen 128x128 tile (d_sae 24576)") + 2 * tot("emit bf16 screen 256x256 tile (d_sae 49152)")
+                + 26 * tot("sparse_finish_kernel<SCREENED>") + 24 * tot("convert_x_kernel"), "source": "profiles/r02_config4_fabric_bytes.json"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def _oracle_check_config4(batch, te, out, dirs, n_rows=8):
+    """CHECKER, outside every timed region: `n_rows` sampled prompts x one z-SAE and one transcoder at FULL width, the
+    pass's active sets, values and contribution scores against the CPU oracle (oracle/encode_ref.py, oracle/lens_ref.py:
+    the restatement of circuit_lens.py:585-653 and :762-766 that tests/golden pins to the reference).  Activations to
+    1e-4 relative (north star); a feature may be missing on one side only if its activation is within 2e-5 of zero."""
+    from oracle.encode_ref import encode_ref
+    from oracle.lens_ref import project_z, sparse_desc
+
+    feat, val, count, recon, scores, counts_host = batch.dictionary_pass(dirs)
+    encs, xs = batch._encoders_and_inputs()
+    rows = torch.linspace(0, batch.n_rows - 1, n_rows).long().tolist()
+    d_all = batch._row_directions(dirs).cpu()
+    ok = True
+    for di in (2 * 5, 2 * 8 + 1):  # the 49152-wide z-SAE of layer 5 and the layer-8 transcoder
+        enc, layer, is_z = encs[di], di // 2, di % 2 == 0
+        w = {n: getattr(enc, n).detach().cpu() for n in ("W_enc", "b_enc", "b_dec", "W_dec")}
+        x = xs[di][rows].cpu()
+        acts = encode_ref(x, w["W_enc"], w["b_enc"], w["b_dec"])
+        for j, r in enumerate(rows):
+            v_ref, i_ref = sparse_desc(acts[j])
+            c = int(counts_host[di, r])
+            got = dict(zip(feat[di, r, :c].tolist(), val[di, r, :c].tolist()))
+            ref = dict(zip(i_ref.tolist(), v_ref.tolist()))
+            for f in set(got) | set(ref):
+                a, b = got.get(f, 0.0), ref.get(f, 0.0)
+                ok = ok and (abs(a - b) <= 1e-4 * max(abs(a), abs(b)) + 2e-5)
+            vecs = w["W_dec"][i_ref] * v_ref[:, None]
+            if is_z:
+                vecs = project_z(vecs, batch.model.W_O[layer].detach().cpu())
+            s_ref = dict(zip(i_ref.tolist(), (vecs.double() @ d_all[r].double()).tolist()))
+            s_got = dict(zip(feat[di, r, :c].tolist(), scores[di, r, :c].tolist()))
+            scale = float(vecs.norm(dim=1).max() * d_all[r].norm()) if len(i_ref) else 1.0
+            for f in set(s_got) & set(s_ref):
+                ok = ok and abs(s_got[f] - s_ref[f]) <= 1e-4 * scale
+    return bool(ok)
+
+
+# ----------------------------------------------------------------------------- config 5 (side object)
+def config5_side_object(device, tokens=16384, launches=12, warm=3, k=20):
+    """BASELINE configs[4], driver-timed as a side object: d_sae 131072 random-init transcoder, bf16 inputs / weights
+    with fp32 accumulation (v_mfma_f32_32x32x16_bf16), fused top-20 -- `launches` launches of `tokens` tokens after
+    `warm` untimed ones (the config's 16 M tokens are 1024 such launches; the rate is size-independent once the lists
+    are warm).  The lists are then verified against the handle's own dense activations of the last batch."""
+    import tsc_hip
+
+    d_sae = 131072
+    W_enc, b_enc, b_dec = make_device_dictionary(d_sae, 555, device)
+    d = tsc_hip.DeviceDict(W_enc, b_enc, b_dec, compute_dtype=tsc_hip.BF16)
+    st = tsc_hip.TopkState(d_sae, k, device)
+    g = torch.Generator(device=device).manual_seed(777)
+    xs = [torch.randn(tokens, D_IN, generator=g, device=device) for _ in range(4)]
+    n = 0
+    for _ in range(warm):
+        d.encode_topk(xs[n % 4], n * tokens, st)
+        n += 1
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(launches):
+        d.encode_topk(xs[n % 4], n * tokens, st)
+        n += 1
+    e1.record()
+    vals, idx = st.finalize()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kern_s = e0.elapsed_time(e1) * 1e-3
+    flops = 2.0 * D_IN * d_sae * tokens * launches
+    last = n - 1
+
+    class _E:  # verify_slice wants an engine with encode_dense
+        @staticmethod
+        def encode_dense(dd, x):
+            return dd.encode_dense(x)
+
+    verified = verify_slice(_E, d, xs[last % 4], last * tokens, vals, idx, chunk=2048)
+    d.close()
+    return {
+        "workload": f"configs[4]: d_sae {d_sae} random-init transcoder, bf16 MFMA encode + fused top-{k}, {tokens} tokens per launch",
+        "value": tokens * launches / wall, "unit": "tokens/s", "ms_per_launch": kern_s / launches * 1e3,
+        "dtype": "bf16 operands, fp32 accumulate", "verified": verified,
+        "roofline": {"bound": "mfma", "kernel": "encode_f32_kernel<TOPK, BF16>", "achieved": flops / kern_s / 1e12, "peak": 2500.0,
+                     "unit": "TFLOP/s", "frac": flops / kern_s / 1e12 / 2500.0,
+                     "note": "x conversion and floor kernels included; dense bf16 peak"},
+    }
+
+
+# ----------------------------------------------------------------------------- the product sweep (side object)
+def product_sweep_side_object(engine, dicts, widths, xs, n_batches, B, K, W, k, rank_base, fp32_outs):
+    """The sweep as the PRODUCT runs it (topk_scan.HipTopkEngine, the default engine of MaxActSweep / sweep_model): every
+    dictionary starts cold on the fp32 kernel and switches to the screened top-k once its lists are warm -- over the same
+    W + K batches and token ids as the headline run, timed from the first batch, so the cold phase is IN the number.
+    The finished lists must equal the fp32 run's bit for bit."""
+    from _dictionary import HipDictionaryMixin
+    from topk_scan import HipTopkEngine
+
+    class _SweepDict(HipDictionaryMixin, torch.nn.Module):
+        def __init__(self, W_enc, b_enc, b_dec):
+            super().__init__()
+            self.W_enc, self.b_enc, self.b_dec = (torch.nn.Parameter(t, requires_grad=False) for t in (W_enc, b_enc, b_dec))
+            # the sweep never decodes: a one-row decoder keeps the handle's interface without 2 GB of zeros
+            self.W_dec = torch.nn.Parameter(torch.zeros(4, D_IN, device=W_enc.device), requires_grad=False)
+
+        def _out_bias(self):
+            return self.b_dec
+
+    mods = [_SweepDict(*d._keep[:3]) for d in dicts]
+    engines = [HipTopkEngine(m, k) for m in mods]
+    for m in mods:
+        m.device_dict(screened=True)  # handle registration (bf16 copy, norms) is set-up, not sweep
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(W + K):
+        for i, e in enumerate(engines):
+            e.update(xs[s % n_batches][i], rank_base + s * B)
+    outs = [e.finalize() for e in engines]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    same = all(torch.equal(v, fv) and torch.equal(ix, fi) for (v, ix), (fv, fi) in zip(outs, fp32_outs))
+    for m in mods:
+        for attr in ("_hip", "_hip_screen"):
+            h = m.__dict__.get(attr)
+            if h is not None:
+                h.close()
+    return {
+        "what": "HipTopkEngine (product default) from cold lists: fp32 kernel for each dictionary's first "
+                f"{HipTopkEngine.SCREEN_AFTER_TOKENS} rows, screened top-k after; {W + K} batches of {B} positions, cold phase timed",
+        "value": (W + K) * B / elapsed, "unit": "positions/s", "ms_per_step": elapsed / (W + K) * 1e3,
+        "lists_bit_identical_to_fp32_path": same,
+    }
 
 
 # ----------------------------------------------------------------------------- traffic
@@ -472,6 +624,7 @@ def parse_args(argv):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-config4", action="store_true")
+    ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--no-screened", action="store_true")
     # rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0, collectives over gloo
     ap.add_argument("--rehearse-on-one-gpu", action="store_true")
@@ -678,6 +831,17 @@ def main(argv=None):
                                                                  rank_base, outs)
             except Exception as e:  # noqa: BLE001
                 out["screened_topk"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_screened and engine.name == "hip" and not args.dict_widths:
+            try:
+                out["product_sweep"] = product_sweep_side_object(engine, dicts, widths, xs, n_batches, B, K, W, args.k,
+                                                                 rank_base, outs)
+            except Exception as e:  # noqa: BLE001
+                out["product_sweep"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_config5 and engine.name == "hip" and not args.dict_widths:
+            try:
+                out["config5"] = config5_side_object(device)
+            except Exception as e:  # noqa: BLE001
+                out["config5"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_config4 and engine.name == "hip":
             del xs, dicts, states
             torch.cuda.empty_cache()

@@ -31,6 +31,7 @@ extern "C" {
 
 #define TSC_F32 0  /* fp32 inputs/weights, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)            */
 #define TSC_BF16 1 /* bf16-rounded inputs/weights, fp32 accumulate (v_mfma_f32_32x32x16_bf16)  */
+#define TSC_SCREEN_MAX_ROWS 65536 /* rows of the bf16 staging buffer of a TSC_BF16 / TSC_F32_SCREEN handle (100 MB at d_in 768) */
 #define TSC_F32_SCREEN 2 /* TSC_F32 for every entry point; tsc_sparse_lens_pass screens with the bf16 MFMA first */
 
 typedef struct tsc_dict tsc_dict_t; /* opaque: one transcoder or z-SAE resident on one GPU */
@@ -47,7 +48,7 @@ const char *tsc_last_error(void);
  * out_bias [d_out] (= b_dec_out for a transcoder, = b_dec for a z-SAE; mlp_transcoder.py:131-147,
  * z_sae.py:62).  W_dec/out_bias may be NULL if only encode entry points are used.
  * compute_dtype TSC_BF16 (needs d_in % 128 == 0) makes one device-side transposed bf16 copy of W_enc and
- * a 32768-row bf16 staging buffer for x (hipMalloc, freed by destroy); such a handle computes
+ * a TSC_SCREEN_MAX_ROWS-row bf16 staging buffer for x (hipMalloc, freed by destroy); such a handle computes
  * relu(bf16(x - b_dec) @ bf16(W_enc) + b_enc) with fp32 accumulation, and its calls must not overlap
  * on different streams (they share the staging buffer).
  * compute_dtype TSC_F32_SCREEN (needs d_in % 128 == 0) is TSC_F32 plus the operands of the bf16 SCREEN of
@@ -155,7 +156,7 @@ int tsc_encode_topk_static(const tsc_dict_t *dict, const float *x, int64_t M, in
 
 /*
  * tsc_encode_topk at the bf16 matrix rate with the lists of tsc_encode_topk, BIT FOR BIT (TSC_F32_SCREEN handles).
- * Per chunk of 32768 rows: (1) the bf16 MFMA kernel computes bf16(x - b_dec) @ bf16(W_enc) + b_enc + margin[n]
+ * Per chunk of TSC_SCREEN_MAX_ROWS rows: (1) the bf16 MFMA kernel computes bf16(x - b_dec) @ bf16(W_enc) + b_enc + margin[n]
  * (margin: the proven bound of tsc_sparse_lens_pass) and queues every (token, feature) pair whose value reaches the
  * feature's floor -- the k-th best over all slots before the call, state->floor, required -- one queue per
  * workgroup in `workspace`; (2) a second kernel recomputes the queued pairs exactly in fp32, in the accumulation
@@ -258,7 +259,7 @@ int tsc_contrib_scores(const tsc_dict_t *dict, const int32_t *feat, const float 
  * max_active then means "the CANDIDATES overflowed" (an upper bound of the active count): retry with that capacity.
  * screen_row_bound: device pointer to TWO floats >= (bound[0], bound[1]) above (tsc_hip.screen_row_bound computes them
  * with torch), or NULL = the library computes them (one more small kernel); ignored by other
- * handles.  At most 32768 rows per call on such a handle.
+ * handles.  At most TSC_SCREEN_MAX_ROWS rows per call on such a handle.
  */
 #define TSC_LENS_COUNT_IS_ZERO 1
 #define TSC_LENS_NO_SCREEN 2

@@ -333,7 +333,7 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
     dev = inputs[0].device
     d_out = encoders[0].W_dec.shape[1]
     cap = max(1, min(int(max_active), tsc_hip.LENS_PASS_MAX_ACTIVE))
-    screened = screened and rows <= 32768
+    screened = screened and rows <= tsc_hip.SCREEN_MAX_ROWS
 
     def look_up():
         hs = [enc.device_dict(screened=screened) for enc in encoders]
@@ -836,7 +836,7 @@ class BatchedCircuitLens:
     def _row_bounds(self) -> Optional[torch.Tensor]:
         """Row bounds of the bf16 screen for every dictionary ``[D]``: they depend on the inputs only, so one
         batched computation serves every pass over this batch."""
-        if self.n_rows > 32768 or not self.screened:
+        if self.n_rows > 65536 or not self.screened:  # tsc_hip.SCREEN_MAX_ROWS
             return None
         if getattr(self, "_bounds", None) is None:
             import tsc_hip

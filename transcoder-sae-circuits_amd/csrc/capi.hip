@@ -345,7 +345,8 @@ int tsc_sparse_lens_pass(const tsc_dict_t *d, const float *x, int64_t M, int max
     a.sp_feat = feat; a.sp_val = val; a.sp_count = count; a.max_active = max_active;
     if (d->compute_dtype == TSC_F32_SCREEN && d->W_enc_t && !(flags & TSC_LENS_NO_SCREEN)) {
         // bf16 MFMA screen (16x the fp32 matrix rate) -> candidates; the finish kernel recomputes them exactly in fp32
-        if (M > 32768) return tsc_fail(TSC_ERR_UNSUPPORTED, "screened lens pass takes at most 32768 rows per call (got %lld)", (long long)M);
+        if (M > TSC_SCREEN_MAX_ROWS)
+            return tsc_fail(TSC_ERR_UNSUPPORTED, "screened lens pass takes at most %d rows per call (got %lld)", TSC_SCREEN_MAX_ROWS, (long long)M);
         if (!screen_row_bound) {
             rc = tsc_launch_row_bound(x, M, d->d_in, d->b_dec, d->screen_bound, s);
             if (rc) return rc;
@@ -379,7 +380,7 @@ int tsc_sparse_lens_emit_many(int n_dicts, const tsc_dict_t *const *dicts, const
                 return tsc_fail(TSC_ERR_ARG, "lens_emit_many: dictionary handle %d is listed twice (entries %d and %d)", i, j, i);
     // Screening handles of one input width: ONE grouped launch on streams[0] (a 512-row emit is 1.5 rounds of
     // single-tile workgroups; emits on different streams do not pack into each other's idle half round, one grid does)
-    bool group = n_dicts > 1 && n_dicts <= 32 && M <= 32768 && !(flags & TSC_LENS_NO_SCREEN);
+    bool group = n_dicts > 1 && n_dicts <= 32 && M <= TSC_SCREEN_MAX_ROWS && !(flags & TSC_LENS_NO_SCREEN);
     for (int i = 0; i < n_dicts && group; ++i)
         group = dicts[i] && dicts[i]->compute_dtype == TSC_F32_SCREEN && dicts[i]->W_enc_t && dicts[i]->W_enc_bf16 &&
                 dicts[i]->d_in == dicts[0]->d_in && x[i] && aligned16(x[i]);

@@ -22,7 +22,6 @@
 
 namespace {
 
-constexpr long long TSC_BF16_WS_ROWS = 32768;
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
     unsigned u = __float_as_uint(f);

@@ -25,7 +25,7 @@ namespace {
 constexpr int SQ_CAP_256 = 8192;   // queue entries per workgroup with 256-wide column tiles (half with 128-wide ones)
 constexpr int SQ_BATCH = 1024;
 constexpr int SQ_KL = 20;  // list length up to which an owner mirrors its list's values in LDS
-constexpr long long SQ_CHUNK_ROWS = 32768;  // = the bf16 staging buffer of the handle; row ids fit 15 bits
+constexpr long long SQ_CHUNK_ROWS = TSC_BF16_WS_ROWS;  // = the bf16 staging buffer of the handle; a queue entry keeps 24 bits of row
 
 __device__ __forceinline__ bool below(float v, long long id, float w, long long wid) {
     return v < w || (v == w && id > wid);  // (v, id) ranks below (w, wid): value descending, token id ascending

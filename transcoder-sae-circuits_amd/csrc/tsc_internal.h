@@ -17,6 +17,11 @@ struct tsc_dict {
     float *screen_bound;                                    // owned (TSC_F32_SCREEN only): two floats, the row bounds of the current call
 };
 
+// rows of a handle's bf16 staging buffer for x = rows per chunk of every bf16 / screened call (include/tsc_hip.h:
+// TSC_SCREEN_MAX_ROWS).  65536: one chunk per sweep batch of 512 sequences x 128 positions; the screened top-k's
+// queue entries (row << 8 | column) leave 24 bits for the row.
+constexpr long long TSC_BF16_WS_ROWS = TSC_SCREEN_MAX_ROWS;
+
 // error plumbing (capi.hip)
 int tsc_fail(int code, const char *fmt, ...);
 #define TSC_HIP_CHECK(expr)                                                                  \

@@ -23,7 +23,12 @@ import tsc_hip
 class HipTopkEngine:
     """Running top-k of one dictionary on the GPU."""
 
-    SCREEN_AFTER_TOKENS = 32768  # the first batches run on the fp32 kernel: on cold lists every positive activation is a candidate
+    # The first rows of a sweep run on the fp32 kernel: on empty lists every positive activation is a candidate of the
+    # screen.  16384 rows put ~40 activations into a list of a feature that fires on 0.26 % of the tokens, so its k-th
+    # best already dismisses half of what follows; rarer features stay "cold" for as long as they have fewer than k
+    # activations, which is exactly when their candidates are few.  (Whatever the lists hold, the result is the
+    # fp32 kernel's bit for bit: a queue that overflows makes the library redo the chunk exactly.)
+    SCREEN_AFTER_TOKENS = 16384
 
     def __init__(self, dictionary, k: int = 20, bf16: bool = False, screened: bool = True):
         self.dictionary = dictionary
@@ -34,8 +39,13 @@ class HipTopkEngine:
         self.tokens_seen = 0
 
     def update(self, x: torch.Tensor, token_id_base: int) -> None:
-        warm = self.screened and not self.bf16 and self.tokens_seen >= self.SCREEN_AFTER_TOKENS
-        self.dictionary.encode_topk(x, token_id_base, self.state, bf16=self.bf16, screened=warm)
+        can_screen = self.screened and not self.bf16
+        cold = max(0, min(x.shape[0], self.SCREEN_AFTER_TOKENS - self.tokens_seen)) if can_screen else 0
+        if 0 < cold < x.shape[0]:  # a batch that straddles the warm-up: its head on the fp32 kernel, the rest screened
+            self.dictionary.encode_topk(x[:cold], token_id_base, self.state, bf16=False, screened=False)
+            self.dictionary.encode_topk(x[cold:], token_id_base + cold, self.state, bf16=False, screened=True)
+        else:
+            self.dictionary.encode_topk(x, token_id_base, self.state, bf16=self.bf16, screened=can_screen and cold == 0)
         self.tokens_seen += x.shape[0]
 
     def finalize(self) -> Tuple[torch.Tensor, torch.Tensor]:

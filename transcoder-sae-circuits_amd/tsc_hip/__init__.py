@@ -22,6 +22,7 @@ MAX_DIRS = 8
 LENS_PASS_MAX_ACTIVE = 2048  # tsc_sparse_lens_pass
 TOPK_MERGE_MAX = 2048              # include/tsc_hip.h: TSC_TOPK_MERGE_MAX
 STATIC_FLOOR_MAX_D_SAE = 131072    # include/tsc_hip.h: TSC_STATIC_FLOOR_MAX_D_SAE
+SCREEN_MAX_ROWS = 65536            # include/tsc_hip.h: TSC_SCREEN_MAX_ROWS
 
 # name -> (restype, argtypes); mirrors include/tsc_hip.h one to one
 _c = ctypes
