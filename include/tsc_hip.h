@@ -229,6 +229,28 @@ int tsc_contrib_scores(const tsc_dict_t *dict, const int32_t *feat, const float 
                        int n_dir, float *scores, tsc_stream_t stream);
 
 /*
+ * tsc_contrib_scores (n_dir = 1, a direction per row) for a window of rows of SEVERAL dictionaries in one launch:
+ *   scores[i, m, e] = val[i, m, e] * dot(W_dec_i[feat[i, m, e], :], dirs[i][m * dir_row_stride ..]),  e < count[i, m],
+ * where feat / val / count are windows of M rows of stacked pass outputs whose dictionaries lie dict_pitch_rows rows
+ * apart (feat / val: [.., dict_pitch_rows, max_active], count: [.., dict_pitch_rows]; pass pointers to the window's
+ * first row of dictionary 0), dirs is a HOST array of n_dicts device pointers (dir_row_stride 0 = one direction for
+ * all M rows), and scores [n_dicts, M, out_max_active] is compact, zero beyond count.  Optional compact copies of the
+ * window: feat_out [n_dicts, M, out_max_active] (-1 beyond count), count_out [n_dicts, M] -- what tsc_lens_assemble
+ * takes.  out_max_active (0 = max_active) is the row pitch of these outputs: a caller that knows the window's counts
+ * (it read them after the pass) asks for lists just long enough, so that the assemble step does not walk a capacity
+ * that one crowded position of the pass dictated; counts above it are clamped to it.
+ * This is the per-node lens call of the circuit search -- ONE position against one direction over the components of
+ * all dictionaries (circuit_lens.py:753-778, 940-968, 974-1004, 1031-1054, 1085-1107: `vectors @ direction` on the
+ * feature rows) -- without building the [components, d_model] matrix and without a launch per dictionary; attention
+ * dictionaries take dirs' = W_O[layer] @ dir as in tsc_contrib_scores.  Bit-identical to tsc_contrib_scores.
+ * n_dicts <= 32, same d_out for all.
+ */
+int tsc_contrib_scores_many(int n_dicts, const tsc_dict_t *const *dicts, int64_t M, int64_t dict_pitch_rows, int max_active,
+                            const int32_t *feat, const float *val, const int32_t *count, const float *const *dirs,
+                            int64_t dir_row_stride, float *scores, int32_t *feat_out, int32_t *count_out,
+                            int out_max_active, tsc_stream_t stream);
+
+/*
  * The CircuitLens decomposition of a BATCH of positions against one dictionary in two launches: the sparse emit
  * of tsc_encode_sparse, then one kernel that, per row, orders the emitted pairs (value descending) and reads each
  * active feature's W_dec row once for both

@@ -576,3 +576,45 @@ def test_grouped_finish_equals_the_per_dictionary_lens_pass(screened, m):
         mixed = [hs[0], _dd(ws[1])[0], hs[2]]
         with pytest.raises(tsc_hip.TscError):
             tsc_hip.sparse_lens_finish_many(mixed, xs, feat, val, count)
+
+
+def test_fused_per_node_lens_equals_the_vectors_path():
+    """The per-node lens calls of the circuit search (unembed, direction, MLP-feature, V, Q, K lenses) through the fused
+    path -- W_O pull-back, tsc_contrib_scores_many, tsc_rowdot_many, tsc_lens_assemble with the cut-off, no
+    [components, d_model] matrix -- against the reference-shaped path ``normalize(vectors_before @ direction).topk``:
+    same components in the same order (a differing rank only at a near-tie of the reference-shaped values), same
+    values to the reference's ATOL; single-prompt lens and a per-prompt view of a batch."""
+    from circuit_lens import BatchedCircuitLens, CircuitLens
+
+    g3, g4, model, z_w, t_w = _lens_world()
+    g5, *_, prompts = gi.g5_inputs()
+    single = CircuitLens(gi.PROMPT)
+    view = BatchedCircuitLens([p["text"] for p in prompts[:3]] + [gi.PROMPT], positions="all").lens(3)
+    gen = torch.Generator().manual_seed(12)
+    for lens in (single, view):
+        n = lens.n_tokens
+        mf, _, _ = lens._active("mlp", 1, n - 3)
+        zf, _, _ = lens._active("attn", 2, n - 3)
+        calls = [
+            lambda l: l.get_unembed_lens(int(l.tokens[0, n - 2]), n - 3, visualize=False, k=10),
+            lambda l: l.get_direction_lens(torch.randn(768, generator=gen.manual_seed(3)).to(DEV), 4, visualize=False, k=7),
+            lambda l: l.get_mlp_feature_lens_at_seq(1, n - 3, int(mf[0]), visualize=False, k=10),
+            lambda l: l.get_mlp_feature_lens_at_seq(0, 2, int(l._active("mlp", 0, 2)[0][0]), visualize=False, k=10),
+            lambda l: l.get_v_lens_at_seq(2, 5, n - 3, int(zf[0]), visualize=False, k=10),
+            lambda l: l.get_q_lens_on_head_seq(1, 3, 2, n - 3, visualize=False, k=10),
+            lambda l: l.get_k_lens_on_head_seq(2, 7, 2, n - 3, visualize=False, k=10),
+        ]
+        for call in calls:
+            lens.FUSED_LENS = True
+            got, lazy = call(lens)
+            lens.FUSED_LENS = False
+            want, af = call(lens)
+            assert len(got) == len(want) and len(got) > 0
+            gv, wv = torch.tensor([v for _, v in got]), torch.tensor([v for _, v in want])
+            _close(gv, wv, atol=ATOL)
+            mism = [j for j, (a, b) in enumerate(zip(_ids(got), _ids(want))) if a != b]
+            _assert_mismatches_are_near_ties(mism, wv.tolist() + [float("-inf")])
+            assert [r.tuple_id[0] for r, _ in got] == [r.tuple_id[0] for r, _ in want] or mism
+            # the stand-in for ActiveFeatures builds the real one on demand
+            assert lazy.keys == af.keys and torch.equal(lazy.features, af.features)
+        lens.FUSED_LENS = True

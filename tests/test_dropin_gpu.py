@@ -184,7 +184,7 @@ def test_circuit_lens_scores_match_reference():
     tok = int(cl.tokens[0, seq + 1])
     _close(af.vectors @ cl.model.W_U[:, tok], g4["unembed_raw"], atol=ATOL)
     runs, af2 = cl.get_unembed_lens(tok, seq, visualize=False, k=10)
-    assert af2 is af and _ids(runs) == g4["unembed_top_ids"].tolist()
+    assert af2.vectors is af.vectors and _ids(runs) == g4["unembed_top_ids"].tolist()  # (a stand-in that resolves to the cached object)
     _close(torch.tensor([v for _, v in runs]), g4["unembed_top_vals"], atol=ATOL)
     masked = (af.vectors @ cl.model.W_U[:, tok]).clone()
     masked[:2] = -1e9

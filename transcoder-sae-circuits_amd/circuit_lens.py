@@ -248,8 +248,7 @@ class ComponentLens:
             return cl.get_unembed_lens(d["token_id"], d["seq_index"], **kwargs)
         if self.component == CircuitComponent.UNEMBED_AT_TOKEN:
             seq_index = cl.process_seq_index(d["seq_index"])
-            token_i = cl.tokens[0, seq_index + 1].item()
-            return cl.get_unembed_lens(int(token_i), d["seq_index"], **kwargs)
+            return cl.get_unembed_lens(cl._token_at(seq_index + 1), d["seq_index"], **kwargs)
         if self.component == CircuitComponent.Z_FEATURE:
             return cl.get_head_seq_lens_for_z_feature(d["layer"], d["seq_index"], d["feature"], **kwargs), None
         if self.component == CircuitComponent.Z_SAE_ERROR:
@@ -265,6 +264,19 @@ class ComponentLens:
         if self.component == CircuitComponent.MLP_FEATURE:
             return cl.get_mlp_feature_lens_at_seq(d["layer"], d["seq_index"], d["feature"], **kwargs)
         return [], None
+
+
+class _LazyActiveFeatures:
+    """What the fused lens calls hand back in place of ``ActiveFeatures``: the reference returns the position's
+    ``ActiveFeatures`` next to the ranked list, its callers in the circuit search drop it (circuit_discovery.py:448, 558),
+    and building it -- the ``[components, d_model]`` matrix -- is exactly what the fused path avoids.  Any attribute
+    access builds the real object (``CircuitLens.get_active_features``) and forwards to it."""
+
+    def __init__(self, lens: "CircuitLens", seq_index: int):
+        self.__dict__["_lens"], self.__dict__["_seq"] = lens, seq_index
+
+    def __getattr__(self, name):
+        return getattr(self._lens.get_active_features(self._seq), name)
 
 
 class _PromptCacheView:
@@ -550,6 +562,130 @@ class CircuitLens:
         self._seq_activations[seq_index] = af
         return af
 
+    # ------------------------------------------------------------------ fused per-node lens (no [comp, d_model] matrix)
+    FUSED_LENS = os.environ.get("TSC_LENS_FUSED", "1") != "0"
+
+    def _fused_state(self):
+        """Persistent device buffers and marshalled call tables of :meth:`_fused_lens` (made on first use)."""
+        st = self.__dict__.get("_fused")
+        if st is None:
+            import tsc_hip
+
+            feat, val, count, recons, _, _ = self._ensure_pass()
+            n_layers = self.model.cfg.n_layers
+            encs = []
+            for layer in range(n_layers):
+                encs += [self.z_saes[layer], self.mlp_transcoders[layer]]
+            handles = [e.device_dict() for e in encs]
+            dev, cap, dm = feat.device, feat.shape[2], self.model.W_U.shape[0]
+            w_o = torch.stack([self._w_o_flat(l) for l in range(n_layers)])              # [L, n*d, d_model]
+            ok = all(h.d_out == handles[0].d_out for h in handles) and w_o.shape[1] == dm == handles[0].d_out
+            st = {"ok": ok}
+            if ok:
+                st.update(
+                    group=tsc_hip.ContribGroup(handles), w_o=w_o.contiguous(), n_layers=n_layers, cap=cap,
+                    d=torch.empty(dm, dtype=torch.float32, device=dev), dz=torch.empty(n_layers, dm, dtype=torch.float32, device=dev),
+                    scores=torch.empty(2 * n_layers, 1, cap, dtype=torch.float32, device=dev),
+                    feat=torch.empty(2 * n_layers, 1, cap, dtype=torch.int32, device=dev),
+                    count=torch.empty(2 * n_layers, 1, dtype=torch.int32, device=dev),
+                    head=torch.empty(1, 2, dtype=torch.float32, device=dev),
+                    aux=torch.empty(1, 5 * n_layers, dtype=torch.float32, device=dev),
+                    b_o=torch.stack([self.model.b_O[l] for l in range(n_layers)]).contiguous(),
+                    z_b_dec=torch.stack([self.z_saes[l].b_dec.detach() for l in range(n_layers)]).contiguous(),
+                    t_b_out=torch.stack([self.mlp_transcoders[l].b_dec_out.detach() for l in range(n_layers)]).contiguous(),
+                    z_in=[self._dictionary_input("attn", l) for l in range(n_layers)],  # kept: the tables point into them
+                    tables={}, tags={})
+                st["w_o2d"] = st["w_o"].reshape(n_layers * dm, dm)
+                names = ["scores", "feat", "count", "head", "aux"]
+                width = 2 + 5 * n_layers + 2 * n_layers * cap
+                if width > 15360:  # rows beyond tsc_lens_assemble's LDS are ranked out of its dense outputs
+                    st.update(raw=torch.empty(1, width, dtype=torch.float32, device=dev),
+                              acts=torch.empty(1, width, dtype=torch.float32, device=dev),
+                              mask=torch.empty(1, width, dtype=torch.bool, device=dev))
+                    names += ["raw", "acts", "mask"]
+                st["query"] = tsc_hip.LensQuery(st["group"], feat, val, count, {n: st[n] for n in names}, [3, 2] * n_layers)
+                # per-dictionary directions: z-SAEs see W_O[layer] @ d (row l of dz), transcoders d itself
+                ptrs = st["group"].ds
+                for l in range(n_layers):
+                    ptrs[2 * l] = st["dz"].data_ptr() + 4 * dm * l
+                    ptrs[2 * l + 1] = st["d"].data_ptr()
+            self.__dict__["_fused"] = st
+        return st
+
+    def _fused_tags(self, st, n_groups: int):
+        """``tsc_lens_assemble``'s column labels for the first ``n_groups`` dictionaries (component << 16 | layer)."""
+        t = st["tags"].get(n_groups)
+        if t is None:
+            tags = [0 << 16, 1 << 16]
+            for g in range(n_groups):
+                layer = g // 2
+                tags += [(c << 16) | layer for c in ((2, 3, 4) if g % 2 == 0 else (6, 7))]
+            tags += [((5 if g % 2 == 0 else 8) << 16) | (g // 2) for g in range(n_groups)]
+            t = st["tags"][n_groups] = torch.tensor(tags, dtype=torch.int32, device=st["d"].device)
+        return t
+
+    def _fused_lens(self, direction: torch.Tensor, seq_index: int, before: Optional[Tuple[str, int]], k: int):
+        """``normalize_activations(vectors_before(kind, layer) @ direction)`` of position ``seq_index`` and its top-k as
+        ``[(component, layer, feature, value)]`` -- the list ``ActiveFeatures.get_top_k_features`` returns, including its
+        stop at the first embed / pos_embed row -- in five launches and one device-to-host copy: ``W_O`` pull-back of the
+        direction, ``tsc_contrib_scores_many`` (every dictionary's active features at this position), ``tsc_rowdot_many``
+        (the auxiliary rows), ``tsc_lens_assemble`` over the dictionaries in front of the cut-off.  Returns None when the
+        model's shapes rule the fused path out (the caller then takes the ``vectors`` path)."""
+        import tsc_hip
+
+        st = self._fused_state()
+        n_layers = self.model.cfg.n_layers
+        n_groups = 2 * n_layers if before is None else 2 * before[1] + (1 if before[0] == "mlp" else 0)
+        if not st["ok"] or n_groups == 0 or k > 64:
+            return None
+        feat, val, count, recons, counts, _ = self._ensure_pass()
+        r = self._row(seq_index)
+        # lists just long enough for THIS position (one crowded position of the prompt dictates the pass's capacity)
+        out_cap = (max(1, max(counts[g][r] for g in range(n_groups))) + 63) // 64 * 64
+        with torch.no_grad():
+            st["d"].copy_(direction.reshape(-1))
+            torch.mv(st["w_o2d"], st["d"], out=st["dz"].view(-1))  # W_O[layer] @ d for every layer
+            tab = st["tables"].get(seq_index)
+            if tab is None:
+                dm = st["d"].shape[0]
+                tab = tsc_hip.RowDotTable(2 + 5 * n_layers, 1, dm)
+                row = lambda t: t.reshape(1, dm)  # noqa: E731
+                head, aux, d, dz = st["head"], st["aux"], st["d"], st["dz"]
+                tab.set(0, row(self.cache["embed"][0, seq_index]), None, d, head[:, 0])
+                tab.set(1, row(self.cache["pos_embed"][0, seq_index]), None, d, head[:, 1])
+                for l in range(n_layers):
+                    j = 2 + 5 * l
+                    z_in = st["z_in"][l][seq_index]
+                    tab.set(j, st["b_o"][l], None, d, aux[:, 5 * l])
+                    tab.set(j + 1, row(z_in), row(recons[2 * l][r]), dz[l], aux[:, 5 * l + 1])
+                    tab.set(j + 2, st["z_b_dec"][l], None, dz[l], aux[:, 5 * l + 2])
+                    tab.set(j + 3, row(self.cache["mlp_out", l][0, seq_index]), row(recons[2 * l + 1][r]), d, aux[:, 5 * l + 3])
+                    tab.set(j + 4, st["t_b_out"][l], None, d, aux[:, 5 * l + 4])
+                st["tables"][seq_index] = tab
+            # scores of the position's active features, its auxiliary rows, normalise + rank: three library calls, one
+            # copy to pinned host memory, one synchronisation
+            host = st["query"].run(r, n_groups, k, tab, self._fused_tags(st, n_groups), out_cap)
+        info = host[:4 * k].view(k, 4).tolist()
+        values = host[4 * k:].view(torch.float32).tolist()
+        out = []
+        for (col, comp, layer, feature), v in zip(info, values):
+            if col < 0:
+                break  # fewer than k components
+            out.append((_COMPONENT_ORDER[comp], layer, feature, v))
+            if comp < 2:
+                break  # the reference's loop ends at the first embed / pos_embed row (circuit_lens.py:171-176)
+        return out
+
+    def _fused_runs(self, direction, seq_index: int, before, k):
+        """The fused lens as the reference's lens functions return it: ``([(ComponentLens, value)], active features)``."""
+        top = self._fused_lens(direction, seq_index, before, 10 if k is None else k)
+        if top is None:
+            return None
+        runs = [(ComponentLens(circuit_lens=self, component=component,
+                               run_data={"layer": layer, "seq_index": int(seq_index), "feature": feature}), value)
+                for component, layer, feature, value in top]
+        return runs, _LazyActiveFeatures(self, seq_index)
+
     # ------------------------------------------------------------------ contribution scores (sparse form)
     def contribution_scores(self, kind: str, layer: int, directions: torch.Tensor, seq_index: Optional[int] = None):
         """``feature_act x W_dec row . direction`` for the active features of ``layer``'s dictionary
@@ -577,8 +713,14 @@ class CircuitLens:
 
     def get_unembed_lens_for_prompt_token(self, seq_index: int, visualize=True, k=None):
         seq_index = self.process_seq_index(seq_index)
-        token_i = self.tokens[0, seq_index + 1].item()
-        return self.get_unembed_lens(token_i, seq_index, visualize, k)
+        return self.get_unembed_lens(self._token_at(seq_index + 1), seq_index, visualize, k)
+
+    def _token_at(self, index: int) -> int:
+        """Token id at a position, from a host copy made once (``.item()`` would synchronise on every lens call)."""
+        host = self.__dict__.get("_tokens_host")
+        if host is None:
+            host = self.__dict__["_tokens_host"] = self.tokens[0].tolist()
+        return host[index]
 
     def get_str_token_at_seq(self, seq_index: int):
         return self.model.tokenizer.decode([self.tokens[0, self.process_seq_index(seq_index)]])
@@ -587,6 +729,10 @@ class CircuitLens:
         if isinstance(token_i, str):
             token_i = self.model.to_tokens(token_i, prepend_bos=False)[0]
         seq_index = self.process_seq_index(seq_index)
+        if self.FUSED_LENS and not visualize:
+            fused = self._fused_runs(self.model.W_U[:, token_i], seq_index, None, k)
+            if fused is not None:
+                return fused
         af = self.get_active_features(seq_index)
         activations = self.normalize_activations(af.vectors @ self.model.W_U[:, token_i])
         return self.get_next_lens_runs(af, activations, seq_index,
@@ -596,6 +742,10 @@ class CircuitLens:
     def get_direction_lens(self, direction: torch.Tensor, seq_index: int, visualize=True, k=None):
         """``get_unembed_lens`` for an arbitrary residual direction (e.g. ``TaskEvaluation.logit_difference``)."""
         seq_index = self.process_seq_index(seq_index)
+        if self.FUSED_LENS and not visualize:
+            fused = self._fused_runs(direction.to(self.model.W_U.device, torch.float32), seq_index, None, k)
+            if fused is not None:
+                return fused
         af = self.get_active_features(seq_index)
         activations = self.normalize_activations(af.vectors @ direction.to(af.vectors.device, af.vectors.dtype).reshape(-1))
         return self.get_next_lens_runs(af, activations, seq_index, title="Direction Lens", visualize=visualize, k=k)
@@ -639,6 +789,10 @@ class CircuitLens:
 
     def get_mlp_feature_lens_at_seq(self, layer: int, seq_index: int, feature: int, visualize=True, k=None):
         seq_index = self.process_seq_index(seq_index)
+        if self.FUSED_LENS and not visualize:
+            fused = self._fused_runs(self.mlp_transcoders[layer].W_enc[:, feature], seq_index, ("mlp", layer), k)
+            if fused is not None:
+                return fused
         af = self.get_active_features(seq_index)
         vectors = af.get_vectors_before_comp("mlp", layer)
         activation = self.normalize_activations(vectors @ self.mlp_transcoders[layer].W_enc[:, feature])
@@ -655,6 +809,12 @@ class CircuitLens:
 
     def get_v_lens_at_seq(self, layer: int, head: int, seq_index: int, feature: int, visualize=True, k=None):
         seq_index = self.process_seq_index(seq_index)
+        if self.FUSED_LENS and not visualize:  # (vectors @ W_V) @ w = vectors @ (W_V @ w)
+            d_head = self.model.W_V.shape[-1]
+            w = self.z_saes[layer].W_enc[head * d_head:(head + 1) * d_head, feature]
+            fused = self._fused_runs(self.model.W_V[layer, head] @ w, seq_index, ("attn", layer), k)
+            if fused is not None:
+                return fused
         af = self.get_active_features(seq_index)
         activation = self.normalize_activations(self.get_v_lens_activations(layer, head, seq_index, feature))
         return self.get_next_lens_runs(af, activation, seq_index,
@@ -670,6 +830,11 @@ class CircuitLens:
     def get_q_lens_on_head_seq(self, layer: int, head: int, source_index, destination_index, visualize=True, k=None):
         source_index = self.process_seq_index(source_index)
         destination_index = self.process_seq_index(destination_index)
+        if self.FUSED_LENS and not visualize:
+            direction = self.model.W_Q[layer, head] @ self.cache["k", layer][0, source_index, head]
+            fused = self._fused_runs(direction, destination_index, ("attn", layer), k)
+            if fused is not None:
+                return fused
         af = self.get_active_features(destination_index)
         activation = self.normalize_activations(self.get_q_lens_activations(layer, head, source_index, destination_index))
         return self.get_next_lens_runs(af, activation, destination_index,
@@ -685,6 +850,11 @@ class CircuitLens:
     def get_k_lens_on_head_seq(self, layer: int, head: int, source_index, destination_index, visualize=True, k=None):
         source_index = self.process_seq_index(source_index)
         destination_index = self.process_seq_index(destination_index)
+        if self.FUSED_LENS and not visualize:
+            direction = self.model.W_K[layer, head] @ self.cache["q", layer][0, destination_index, head]
+            fused = self._fused_runs(direction, source_index, ("attn", layer), k)
+            if fused is not None:
+                return fused
         af = self.get_active_features(source_index)
         activation = self.normalize_activations(self.get_k_lens_activations(layer, head, source_index, destination_index))
         return self.get_next_lens_runs(af, activation, source_index,

@@ -463,6 +463,25 @@ int tsc_lens_assemble(int64_t R, int n_head, int n_groups, const int32_t *group_
                                     feat, k, raw, acts, mask, top_values, top_info, (hipStream_t)stream);
 }
 
+int tsc_contrib_scores_many(int n_dicts, const tsc_dict_t *const *dicts, int64_t M, int64_t dict_pitch_rows, int max_active,
+                            const int32_t *feat, const float *val, const int32_t *count, const float *const *dirs,
+                            int64_t dir_row_stride, float *scores, int32_t *feat_out, int32_t *count_out,
+                            int out_max_active, tsc_stream_t stream) {
+    if (n_dicts < 0 || M < 0) return tsc_fail(TSC_ERR_ARG, "negative count");
+    if (n_dicts == 0 || M == 0) return TSC_OK;
+    if (!dicts || !feat || !val || !count || !dirs || !scores) return tsc_fail(TSC_ERR_ARG, "null contrib_scores_many pointer");
+    if (max_active < 1 || dict_pitch_rows < M || out_max_active < 0 || out_max_active > max_active)
+        return tsc_fail(TSC_ERR_ARG, "bad contrib_scores_many shape");
+    for (int i = 0; i < n_dicts; ++i) {
+        if (!dicts[i]) return tsc_fail(TSC_ERR_ARG, "null dictionary handle %d", i);
+        if (!dirs[i] || !aligned16(dirs[i])) return tsc_fail(TSC_ERR_ARG, "direction %d must be a 16-byte aligned device pointer", i);
+    }
+    if (dir_row_stride != 0 && (dir_row_stride < dicts[0]->d_out || (dir_row_stride & 3)))
+        return tsc_fail(TSC_ERR_ARG, "direction row stride must be 0 or >= d_out and a multiple of 4");
+    return tsc_launch_contrib_many(n_dicts, dicts, M, dict_pitch_rows, max_active, feat, val, count, dirs, dir_row_stride,
+                                   scores, feat_out, count_out, out_max_active, (hipStream_t)stream);
+}
+
 int tsc_rowdot_many(int n_terms, const float *const *a, const int64_t *a_stride, const float *const *c,
                     const int64_t *c_stride, const float *const *b, const int64_t *b_stride, float *const *out,
                     const int64_t *out_stride, int64_t R, int d, tsc_stream_t stream) {

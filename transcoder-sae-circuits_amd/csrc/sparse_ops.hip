@@ -220,6 +220,67 @@ __global__ __launch_bounds__(256) void contrib_kernel(const float *W_dec, int d_
     }
 }
 
+// contrib_kernel<1> for the rows of SEVERAL dictionaries in one launch, each with its own direction(s): the per-node lens
+// calls of the circuit search score ONE position against one direction over all 24 dictionaries -- 24 launches of a
+// few microseconds of work each otherwise.  grid = n_dicts * M, one workgroup per (dictionary, row); the (feature,
+// value) lists are read from stacked buffers whose dictionaries lie `pitch_rows` rows apart (a window of M rows of a
+// larger pass), scores -- and optionally the lists themselves -- are written compactly as [n_dicts, M, max_active].
+// Same per-lane arithmetic and reduction order as contrib_kernel<1>: the scores are bit-identical to tsc_contrib_scores.
+constexpr int CM_MAX = 32;
+struct ContribManyArgs {
+    struct One {
+        const float *W_dec, *dirs;
+    } d[CM_MAX];
+    long long M, pitch_rows, dir_stride;
+    int d_out, max_active, out_cap, n;  // out_cap: row pitch of the compact outputs (<= max_active)
+    const int *feat, *count;
+    const float *val;
+    float *scores;
+    int *feat_out, *count_out;  // optional compact copies [n_dicts, M, max_active] / [n_dicts, M]
+};
+__global__ __launch_bounds__(256) void contrib_many_kernel(const ContribManyArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4 *sd = (f32x4 *)smem_raw;  // the row's direction
+    const int di = (int)(blockIdx.x / p.M);  // uniform
+    const long long m = blockIdx.x - di * p.M;
+    const ContribManyArgs::One &o = p.d[di];
+    const int chunks = p.d_out >> 2;
+    for (int i = threadIdx.x; i < chunks; i += 256) sd[i] = ((const f32x4 *)(o.dirs + m * p.dir_stride))[i];
+    __syncthreads();
+    const long long src = (di * p.pitch_rows + m) * p.max_active, dst = ((long long)di * p.M + m) * p.out_cap;
+    int c = p.count[di * p.pitch_rows + m];
+    if (c > p.out_cap) c = p.out_cap;  // (out_cap <= max_active)
+    if (p.count_out && threadIdx.x == 0) p.count_out[(long long)di * p.M + m] = c;
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    for (int e = grp; e < c; e += 16) {
+        const float v = p.val[src + e];
+        const f32x4 *w_row = (const f32x4 *)(o.W_dec + (long long)p.feat[src + e] * p.d_out);
+        float part = 0.f;
+        for (int ch0 = 0; ch0 < chunks; ch0 += 16 * 12) {
+            f32x4 w[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int ch = ch0 + l16 + 16 * j;
+                w[j] = ch < chunks ? w_row[ch] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int ch = ch0 + l16 + 16 * j;
+                if (ch < chunks) {
+                    const f32x4 q = sd[ch];
+                    part += w[j].x * q.x + w[j].y * q.y + w[j].z * q.z + w[j].w * q.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if (l16 == 0) p.scores[dst + e] = part * v;
+    }
+    for (int e = c + threadIdx.x; e < p.out_cap; e += 256) p.scores[dst + e] = 0.f;
+    if (p.feat_out)
+        for (int e = threadIdx.x; e < p.out_cap; e += 256) p.feat_out[dst + e] = e < c ? p.feat[src + e] : -1;
+}
+
 // The CircuitLens pass for a batch of positions after the sparse emit, ONE launch per dictionary: per token,
 // order the emitted (feature, value) pairs (as sparse_sort_kernel), then read each active feature's W_dec row
 // ONCE and use it twice: for the reconstruction (as decode_sparse_kernel) and for the score against the token's
@@ -681,7 +742,9 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const RowDotArgs p) {
     const long long r = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunks = p.d >> 2;
-    for (int j = wave; j < p.n; j += 4) {  // j is wave-uniform: the term's fields are scalar loads
+    // (few rows -- a single-position lens query -- spread the terms over gridDim.y workgroups: one row's 62 dot products
+    // on one workgroup are a chain of 16 dependent round trips)
+    for (int j = blockIdx.y * 4 + wave; j < p.n; j += 4 * gridDim.y) {  // j is wave-uniform: the term's fields are scalar loads
         const RowDotArgs::Term &t = p.t[j];
         const f32x4 *a = (const f32x4 *)(t.a + r * t.sa), *b = (const f32x4 *)(t.b + r * t.sb);
         const f32x4 *c = t.c ? (const f32x4 *)(t.c + r * t.sc) : nullptr;
@@ -894,6 +957,31 @@ int tsc_launch_lens_assemble(long long R, int n_head, int n_groups, const int *g
     return TSC_OK;
 }
 
+int tsc_launch_contrib_many(int n, const tsc_dict *const *dicts, long long M, long long pitch_rows, int max_active,
+                            const int *feat, const float *val, const int *count, const float *const *dirs,
+                            long long dir_stride, float *scores, int *feat_out, int *count_out, int out_cap,
+                            hipStream_t stream) {
+    if (n <= 0 || M <= 0) return TSC_OK;
+    if (n > CM_MAX) return tsc_fail(TSC_ERR_UNSUPPORTED, "at most %d dictionaries per grouped contribution call (got %d)", CM_MAX, n);
+    if ((long long)n * M > 0x7fffffffLL) return tsc_fail(TSC_ERR_UNSUPPORTED, "grouped contribution grid out of range");
+    ContribManyArgs p;
+    memset(&p, 0, sizeof(p));
+    const int d_out = dicts[0]->d_out;
+    if ((size_t)d_out * 4 > 60 * 1024) return tsc_fail(TSC_ERR_UNSUPPORTED, "d_out too large for the LDS staging");
+    for (int i = 0; i < n; ++i) {
+        if (!dicts[i]->W_dec) return tsc_fail(TSC_ERR_ARG, "dictionary %d was created without W_dec", i);
+        if (dicts[i]->d_out != d_out) return tsc_fail(TSC_ERR_ARG, "grouped contribution: dictionary %d has another d_out", i);
+        p.d[i].W_dec = dicts[i]->W_dec;
+        p.d[i].dirs = dirs[i];
+    }
+    p.M = M; p.pitch_rows = pitch_rows; p.dir_stride = dir_stride; p.d_out = d_out; p.max_active = max_active; p.n = n;
+    p.out_cap = out_cap > 0 && out_cap < max_active ? out_cap : max_active;
+    p.feat = feat; p.val = val; p.count = count; p.scores = scores; p.feat_out = feat_out; p.count_out = count_out;
+    hipLaunchKernelGGL(contrib_many_kernel, dim3((unsigned)(n * M)), dim3(256), (size_t)d_out * 4, stream, p);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
 int tsc_launch_rowdot_many(int n, const float *const *a, const long long *sa, const float *const *c, const long long *sc,
                            const float *const *b, const long long *sb, float *const *out, const long long *so,
                            long long R, int d, hipStream_t stream) {
@@ -907,7 +995,8 @@ int tsc_launch_rowdot_many(int n, const float *const *a, const long long *sa, co
             t.a = a[j0 + j]; t.b = b[j0 + j]; t.c = c ? c[j0 + j] : nullptr; t.out = out[j0 + j];
             t.sa = (int)sa[j0 + j]; t.sb = (int)sb[j0 + j]; t.sc = c && sc ? (int)sc[j0 + j] : 0; t.so = (int)so[j0 + j];
         }
-        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)R), dim3(256), 0, stream, p);
+        const unsigned split = R >= 256 ? 1u : (unsigned)((p.n + 3) / 4);
+        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)R, split), dim3(256), 0, stream, p);
         TSC_HIP_CHECK(hipGetLastError());
     }
     return TSC_OK;

@@ -126,6 +126,10 @@ int tsc_launch_sparse_finish(const float *W_dec, const float *bias, int d_out, i
                              long long M, int max_active, const float *dirs, long long dir_stride, float *recon,
                              float *scores, const float *x, const float *W_enc_t, const float *bias_fold, int d_in,
                              hipStream_t stream);
+int tsc_launch_contrib_many(int n, const tsc_dict *const *dicts, long long M, long long pitch_rows, int max_active,
+                            const int *feat, const float *val, const int *count, const float *const *dirs,
+                            long long dir_stride, float *scores, int *feat_out, int *count_out, int out_cap,
+                            hipStream_t stream);
 int tsc_launch_rowdot_many(int n, const float *const *a, const long long *sa, const float *const *c, const long long *sc,
                            const float *const *b, const long long *sb, float *const *out, const long long *so,
                            long long R, int d, hipStream_t stream);

@@ -64,6 +64,9 @@ _SIGNATURES = {
     "tsc_lens_assemble": (_c.c_int, [_c.c_int64, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
                                      _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
                                      _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "tsc_contrib_scores_many": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                           _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                           _c.c_int, _c.c_void_p]),
     "tsc_rowdot_many": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                    _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p]),
     "tsc_project_features": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
@@ -469,13 +472,15 @@ def screen_row_bound(x: torch.Tensor, b_dec: torch.Tensor) -> torch.Tensor:
 
 def lens_assemble(head: torch.Tensor, aux: torch.Tensor, group_aux, scores: torch.Tensor, count: torch.Tensor,
                   k: int = 10, dense: bool = True, column_tags: Optional[torch.Tensor] = None,
-                  feat: Optional[torch.Tensor] = None):
+                  feat: Optional[torch.Tensor] = None, top_out: Optional[torch.Tensor] = None):
     """``tsc_lens_assemble``: normalise-and-rank tail of the CircuitLens pass for ``R`` rows in one launch.
     ``head [R, n_head]``, ``aux [R, sum(group_aux)]``, ``scores [G, R, cap]``, ``count [G, R]`` (int32); optional
     ``column_tags [n_head + sum(group_aux) + G]`` (int32 labels of the column classes) and ``feat [G, R, cap]``.
     Returns ``{"raw", "activations", "mask"}`` (``[R, W]``, only when ``dense``) plus ``top_values [R, k]``,
     ``top_info [R, k, 4]`` (int32: column, tag >> 16, tag & 0xffff, feature id) and its view ``top_columns``
-    (-inf / -1 where a row has fewer than k live columns)."""
+    (-inf / -1 where a row has fewer than k live columns).  ``top_out``: optional preallocated int32 buffer of ``5 R k``
+    elements that receives ``top_info`` (first ``4 R k``) and the bits of ``top_values`` (one device-to-host copy then
+    fetches both)."""
     scores = _dev(scores, torch.float32, "scores")
     count = _dev(count, torch.int32, "count")
     G, R, cap = scores.shape
@@ -494,8 +499,14 @@ def lens_assemble(head: torch.Tensor, aux: torch.Tensor, group_aux, scores: torc
             raise TscError("lens_assemble: feat must be [G, R, cap] like scores")
     W = head.shape[1] + sum(group_aux) + G * cap
     dev = scores.device
-    out = {"top_values": torch.empty(R, k, dtype=torch.float32, device=dev),
-           "top_info": torch.empty(R, k, 4, dtype=torch.int32, device=dev)}
+    if top_out is not None:
+        if top_out.dtype != torch.int32 or top_out.numel() < 5 * R * k or not top_out.is_contiguous() or top_out.device != dev:
+            raise TscError("lens_assemble: top_out must be a contiguous int32 buffer of 5 R k elements on the scores' device")
+        flat = top_out.reshape(-1)
+        out = {"top_values": flat[4 * R * k:5 * R * k].view(torch.float32).view(R, k), "top_info": flat[:4 * R * k].view(R, k, 4)}
+    else:
+        out = {"top_values": torch.empty(R, k, dtype=torch.float32, device=dev),
+               "top_info": torch.empty(R, k, 4, dtype=torch.int32, device=dev)}
     if dense or W > 15360:  # rows that do not fit in LDS are ranked out of the dense outputs
         out["activations"] = torch.empty(R, W, dtype=torch.float32, device=dev)
         out["raw"] = torch.empty(R, W, dtype=torch.float32, device=dev)
@@ -511,6 +522,107 @@ def lens_assemble(head: torch.Tensor, aux: torch.Tensor, group_aux, scores: torc
                                        out["top_info"].data_ptr(), _stream()))
     out["top_columns"] = out["top_info"][:, :, 0]
     return out
+
+
+class ContribGroup:
+    """``tsc_contrib_scores_many`` for a fixed list of dictionaries, marshalled once: scores of a window of rows of
+    stacked pass outputs ``feat / val [D, R, cap]``, ``count [D, R]`` (any slices of a larger pass along R) against
+    per-dictionary directions ``dirs [D, M, d_out]`` (or ``[D, d_out]``: one direction for all rows of a dictionary)."""
+
+    def __init__(self, handles):
+        self.handles = list(handles)
+        n = len(self.handles)
+        self.hs = (ctypes.c_void_p * n)(*[h._handle for h in self.handles])
+        self.ds = (ctypes.c_void_p * n)()
+        self.d_out = self.handles[0].d_out if n else 0
+
+    def scores(self, feat, val, count, row0: int, rows: int, dirs: Optional[torch.Tensor], out: torch.Tensor,
+               feat_out: Optional[torch.Tensor] = None, count_out: Optional[torch.Tensor] = None, n_dicts: Optional[int] = None,
+               dir_stride: int = 0):
+        """``dirs=None``: the direction pointers the caller has put into ``self.ds`` (persistent buffers: nothing to
+        marshal per call), ``dir_stride`` elements apart from row to row (0: one direction for all rows)."""
+        n = len(self.handles) if n_dicts is None else int(n_dicts)
+        if n == 0 or rows == 0:
+            return out
+        cap = feat.shape[2]
+        if feat.stride(2) != 1 or feat.stride(1) != cap or val.stride() != feat.stride() or count.stride(1) != 1 \
+                or count.stride(0) * cap != feat.stride(0):
+            raise TscError("ContribGroup: feat / val / count must be row slices of stacked [D, R, cap] / [D, R] buffers")
+        if feat.dtype != torch.int32 or val.dtype != torch.float32 or count.dtype != torch.int32 or not feat.is_cuda:
+            raise TscError("ContribGroup: feat / count int32, val float32, on the GPU")
+        _dev(out, torch.float32, "out")
+        if out.numel() < n * rows * cap:
+            raise TscError("ContribGroup: out must hold [D, M, cap]")
+        stride = int(dir_stride)
+        if dirs is not None:
+            _dev(dirs, torch.float32, "dirs")
+            stride = 0 if dirs.dim() == 2 else dirs.stride(1)
+            if dirs.shape[0] < n or dirs.shape[-1] != self.d_out:
+                raise TscError("ContribGroup: dirs must be [D, (M,) d_out]")
+            base, step = dirs.data_ptr(), dirs.stride(0) * 4
+            for i in range(n):
+                self.ds[i] = base + i * step
+        with torch.cuda.device(feat.device):
+            _check(lib().tsc_contrib_scores_many(
+                n, self.hs, rows, count.stride(0), cap, feat.data_ptr() + 4 * row0 * cap,
+                val.data_ptr() + 4 * row0 * cap, count.data_ptr() + 4 * row0, self.ds, stride, out.data_ptr(),
+                feat_out.data_ptr() if feat_out is not None else None,
+                count_out.data_ptr() if count_out is not None else None, 0, _stream()))
+        return out
+
+
+class LensQuery:
+    """The three library calls of ONE per-node lens query -- ``tsc_contrib_scores_many`` over the first ``n_groups``
+    dictionaries at one row of a finished pass, ``tsc_rowdot_many`` (the caller's :class:`RowDotTable` for that
+    position), ``tsc_lens_assemble`` -- with every argument that does not change between queries marshalled once.
+    The circuit search makes thousands of such queries; at a few microseconds of GPU work each, the host side of the
+    call IS its cost.  All buffers are the caller's persistent ones (``buf``: name -> tensor, see CircuitLens)."""
+
+    def __init__(self, group: "ContribGroup", feat, val, count, buf: dict, group_aux):
+        cap = feat.shape[2]
+        if feat.stride(2) != 1 or feat.stride(1) != cap or val.stride() != feat.stride() or count.stride(1) != 1 \
+                or count.stride(0) * cap != feat.stride(0):
+            raise TscError("LensQuery: feat / val / count must be row slices of stacked [D, R, cap] / [D, R] buffers")
+        self.group, self.cap, self.pitch = group, cap, count.stride(0)
+        self.feat_ptr, self.val_ptr, self.count_ptr = feat.data_ptr(), val.data_ptr(), count.data_ptr()
+        self.keep = (feat, val, count, buf)
+        self.device = feat.device
+        self.p = {n: t.data_ptr() for n, t in buf.items()}
+        self.group_aux = [int(a) for a in group_aux]
+        self.ga = (ctypes.c_int32 * len(self.group_aux))(*self.group_aux)
+        self.top: dict = {}
+        self.fn = lib()
+
+    def run(self, row: int, n_groups: int, k: int, table: "RowDotTable", tags: torch.Tensor, out_cap: int = 0) -> torch.Tensor:
+        """Returns a pinned host int32 tensor ``[5 k]``: ``top_info [k, 4]`` then the bits of ``top_values [k]``.
+        ``out_cap``: list length of the compact per-query buffers (>= the row's largest count; 0 = the pass's capacity)."""
+        fn, p, cap = self.fn, self.p, self.cap
+        oc = cap if out_cap <= 0 or out_cap > cap else int(out_cap)
+        wide = 2 + sum(self.group_aux[:n_groups]) + n_groups * oc > 15360
+        if wide and "raw" not in p:
+            raise TscError("LensQuery: a row this wide needs the raw / acts / mask buffers")
+        # (a prefix of the auxiliary columns of ONE row is contiguous: the same buffers serve every cut-off)
+        top = self.top.get(k)
+        if top is None:
+            top = self.top[k] = (torch.empty(5 * k, dtype=torch.int32, device=self.device),
+                                 torch.empty(5 * k, dtype=torch.int32).pin_memory())
+        dev_top, host_top = top
+        stream = torch.cuda.current_stream(self.device)
+        s = stream.cuda_stream
+        with torch.cuda.device(self.device):
+            _check(fn.tsc_contrib_scores_many(n_groups, self.group.hs, 1, self.pitch, cap, self.feat_ptr + 4 * row * cap,
+                                              self.val_ptr + 4 * row * cap, self.count_ptr + 4 * row, self.group.ds, 0,
+                                              p["scores"], p["feat"], p["count"], oc, s))
+            _check(fn.tsc_rowdot_many(table.n, table.a, table.sa, table.c, table.sc, table.b, table.sb, table.out, table.so,
+                                      1, table.d, s))
+            _check(fn.tsc_lens_assemble(1, 2, n_groups, self.ga, oc, p["head"], p["aux"], p["scores"], p["count"],
+                                        tags.data_ptr(), p["feat"], k, p.get("raw") if wide else None,
+                                        p.get("acts") if wide else None, p.get("mask") if wide else None,
+                                        dev_top.data_ptr() + 16 * k,
+                                        dev_top.data_ptr(), s))
+            host_top.copy_(dev_top, non_blocking=True)
+            stream.synchronize()
+        return host_top
 
 
 class RowDotTable:
