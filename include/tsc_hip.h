@@ -199,6 +199,19 @@ int tsc_encode_sparse(const tsc_dict_t *dict, const float *x, int64_t M, int max
                       int32_t *feat, float *val, int32_t *count, tsc_stream_t stream);
 
 /*
+ * The sparse form of a dense activation matrix acts [M, d_sae] (e.g. tsc_encode_dense's output): per row the positive
+ * entries as feat / val [M, max_active] in a FIXED order (not sorted by value; a function of the column only), count[m]
+ * = their true number (entries beyond max_active are dropped: check count), or -1 - that number for a row that holds a
+ * negative or NaN entry (not the output of a ReLU; a negative count makes every consumer skip the row's list).  With tsc_decode_sparse this replaces the
+ * decoder half of SparseTranscoder.forward / ZSAE.forward on many rows -- `feature_acts @ W_dec` (mlp_transcoder.py:
+ * 128-138, z_sae.py:62) multiplies a matrix that is 99.7 % zeros: 618 GFLOP per 16384 x 24576 batch -- by one streaming
+ * read of the activations and a gather of the active features' W_dec rows.  The reconstruction then comes from exactly
+ * the activations the caller gets back.  d_sae % 4 == 0, acts 16-byte aligned.
+ */
+int tsc_dense_to_sparse(const float *acts, int64_t M, int d_sae, int max_active, int32_t *feat, float *val, int32_t *count,
+                        tsc_stream_t stream);
+
+/*
  * rows[i, :] = val[i] * W_dec[feat[i], :] for i < n.  Replaces `W_dec[idx] * vals.unsqueeze(-1)`
  * (circuit_lens.py:616, 651-653, 1220-1222).  An entry with feat[i] outside 0..d_sae-1 (the padding value -1
  * of tsc_encode_sparse's rows) gives a zero row.

@@ -309,3 +309,50 @@ def test_sweep_checkpoint_and_resume_on_gpu(tmp_path):
     b.feed({"mlp_8": x[1500:]}, b.tokens_seen)
     v, i = b.result()["mlp_8"]
     assert torch.equal(v, ev) and torch.equal(i, ei)
+
+
+def test_forward_decodes_from_the_sparse_form_on_many_rows():
+    """``SparseTranscoder.forward`` / ``ZSAE.forward`` on >= 256 rows: the decoder half runs as tsc_dense_to_sparse +
+    tsc_decode_sparse on the activations the caller gets back.  Same reconstruction as the dense product (fp32 sums in
+    another order), dense fallback for few rows, for a row with more positives than the lists hold and for activations a
+    hook has made negative."""
+    import load_model_and_encoders as lme
+    import tsc_hip
+
+    w = gi.g1_full_weights()
+    tc = lme.build_transcoder(w, 0, DEV)
+    x = torch.randn(700, 768, generator=torch.Generator().manual_seed(3)).to(DEV)
+    with torch.no_grad():
+        sae_out, acts = tc(x)[:2]
+        dense = acts @ tc.W_dec + tc.b_dec_out
+        assert int((acts > 0).sum(1).max()) <= tsc_hip.DeviceDict.DECODE_SPARSE_CAPACITY
+        assert tc.device_dict().decode_dense_acts(acts) is not None           # the sparse route was taken ...
+        _close(sae_out, dense, atol=1e-5)                                      # ... and agrees with the dense product
+        assert torch.equal(tc(x)[0], sae_out)                                  # fixed summation order: reproducible
+        few = tc(x[:100])[0]
+        assert tc.device_dict().decode_dense_acts(acts[:100]) is None and torch.equal(few, acts[:100] @ tc.W_dec + tc.b_dec_out)
+        # the lists are the positives of each row in a fixed order
+        m, cap = 300, 64
+        feat = torch.empty(m, cap, dtype=torch.int32, device=DEV)
+        val = torch.empty(m, cap, device=DEV)
+        count = torch.empty(m, dtype=torch.int32, device=DEV)
+        a = acts[:m].contiguous()
+        a[7, 5] = -1.0
+        a[9, 100] = float("nan")
+        tsc_hip._check(tsc_hip.lib().tsc_dense_to_sparse(a.data_ptr(), m, a.shape[1], cap, feat.data_ptr(), val.data_ptr(),
+                                                         count.data_ptr(), None))
+        torch.cuda.synchronize()
+        for r in (0, 1, 150, 299):
+            pos = (a[r] > 0).nonzero().flatten()
+            c = int(count[r])  # (rows 7 and 9 are not among these)
+            assert c == pos.numel()
+            got = dict(zip(feat[r, :min(c, cap)].tolist(), val[r, :min(c, cap)].tolist()))
+            assert len(got) == min(c, cap) and all(float(a[r, f]) == v for f, v in got.items())
+        assert int(count[7]) == -1 - int((a[7] > 0).sum()) and int(count[9]) < 0   # not ReLU outputs: flagged, lists skipped
+        assert tc.device_dict().decode_dense_acts(a) is None                   # -> the caller multiplies densely
+        # z-SAE forward takes the same route
+        wz = gi.g1_inputs()[2]
+        zs = lme.build_zsae(wz, 0, DEV)
+        xz = torch.randn(400, 768, generator=torch.Generator().manual_seed(4)).to(DEV)
+        _, rec, za, _, _ = zs(xz)
+        _close(rec, za @ zs.W_dec + zs.b_dec, atol=1e-5)

@@ -503,6 +503,16 @@ int tsc_rowdot_many(int n_terms, const float *const *a, const int64_t *a_stride,
                                   (const long long *)b_stride, out, (const long long *)out_stride, R, d, (hipStream_t)stream);
 }
 
+int tsc_dense_to_sparse(const float *acts, int64_t M, int d_sae, int max_active, int32_t *feat, float *val, int32_t *count,
+                        tsc_stream_t stream) {
+    if (M < 0) return tsc_fail(TSC_ERR_ARG, "negative row count");
+    if (M == 0) return TSC_OK;
+    if (d_sae <= 0 || (d_sae & 3)) return tsc_fail(TSC_ERR_UNSUPPORTED, "d_sae %d must be a positive multiple of 4", d_sae);
+    if (max_active < 1) return tsc_fail(TSC_ERR_ARG, "max_active %d < 1", max_active);
+    if (!acts || !feat || !val || !count || !aligned16(acts)) return tsc_fail(TSC_ERR_ARG, "bad dense_to_sparse pointer");
+    return tsc_launch_dense_to_sparse(acts, M, d_sae, max_active, feat, val, count, (hipStream_t)stream);
+}
+
 int tsc_decode_rows(const tsc_dict_t *d, const int32_t *feat, const float *val, int64_t n, float *rows,
                     tsc_stream_t stream) {
     int rc = check_decoder(d);

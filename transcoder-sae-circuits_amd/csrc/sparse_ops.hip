@@ -80,6 +80,54 @@ __global__ __launch_bounds__(256) void sparse_sort_kernel(int *feat, float *val,
     }
 }
 
+// Dense activations -> per-row (feature, value) lists: one wavefront per row walks the row in coalesced 1-KiB steps
+// (eight in flight), positives are compacted with ballots -- list position = positives before the element in the order
+// (step, component, lane), no atomics -- so the order, and with it the summation order of a later decode, is fixed.
+// count[m] is the true number of positives (entries beyond max_active are dropped: the caller checks); a row that holds a
+// negative or NaN entry (not the output of a ReLU) reports -1 - that number: NEGATIVE, so that a decode queued before the
+// caller has looked reads none of its list (every consumer clamps its loop at count) instead of unwritten entries.
+__global__ __launch_bounds__(256) void dense_to_sparse_kernel(const float *__restrict__ acts, long long M, int N, int max_active,
+                                                             int *__restrict__ feat, float *__restrict__ val, int *__restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const long long m = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (m >= M) return;
+    const f32x4 *row = (const f32x4 *)(acts + m * N);
+    int *frow = feat + m * max_active;
+    float *vrow = val + m * max_active;
+    const int chunks = N >> 2;
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    int base = 0;
+    bool odd = false;
+    for (int c0 = 0; c0 < chunks; c0 += 64 * 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ch = c0 + 64 * u + lane;
+            v[u] = ch < chunks ? __builtin_nontemporal_load(row + ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool hit = v[u][j] > 0.f;
+                odd |= !(v[u][j] >= 0.f);
+                const unsigned long long mask = __ballot(hit);
+                if (mask) {  // wave-uniform
+                    if (hit) {
+                        const int pos = base + __popcll(mask & below);
+                        if (pos < max_active) {
+                            frow[pos] = (c0 + 64 * u + lane) * 4 + j;
+                            vrow[pos] = v[u][j];
+                        }
+                    }
+                    base += __popcll(mask);
+                }
+            }
+    }
+    if (__ballot(odd)) base = -1 - base;
+    if (lane == 0) count[m] = base;
+}
+
 // one wavefront per row; each lane moves float4 chunks
 __global__ __launch_bounds__(256) void decode_rows_kernel(const float *W_dec, int d_sae, int d_out, const int *feat,
                                                          const float *val, long long n, float *rows) {
@@ -840,6 +888,17 @@ int tsc_launch_sparse_sort(int *feat, float *val, const int *count, long long M,
     }
     hipLaunchKernelGGL(sparse_sort_kernel, dim3((unsigned)M), dim3(256), lds, stream, feat, val, count,
                        max_active);
+    TSC_HIP_CHECK(hipGetLastError());
+    return TSC_OK;
+}
+
+int tsc_launch_dense_to_sparse(const float *acts, long long M, int N, int max_active, int *feat, float *val, int *count,
+                               hipStream_t stream) {
+    if (M <= 0) return TSC_OK;
+    const long long blocks = (M + 3) / 4;
+    if (blocks > 0x7fffffffLL) return tsc_fail(TSC_ERR_UNSUPPORTED, "dense_to_sparse grid out of range");
+    hipLaunchKernelGGL(dense_to_sparse_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, acts, M, N, max_active, feat, val,
+                       count);
     TSC_HIP_CHECK(hipGetLastError());
     return TSC_OK;
 }

@@ -106,6 +106,8 @@ int tsc_launch_topk_merge(const float *vals, const long long *idx, int n_lists, 
 // sparse_ops.hip
 int tsc_launch_sparse_sort(int *feat, float *val, const int *count, long long M, int max_active,
                            hipStream_t stream);
+int tsc_launch_dense_to_sparse(const float *acts, long long M, int N, int max_active, int *feat, float *val, int *count,
+                               hipStream_t stream);
 int tsc_launch_decode_rows(const float *W_dec, int d_sae, int d_out, const int *feat, const float *val,
                            long long n, float *rows, hipStream_t stream);
 int tsc_launch_decode_sparse(const float *W_dec, const float *bias, int d_out, const int *feat,

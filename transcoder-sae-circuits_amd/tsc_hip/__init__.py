@@ -48,6 +48,8 @@ _SIGNATURES = {
     "tsc_topk_finalize": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "tsc_encode_sparse": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p,
                                      _c.c_void_p, _c.c_void_p]),
+    "tsc_dense_to_sparse": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                       _c.c_void_p]),
     "tsc_decode_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p]),
     "tsc_decode_sparse": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int,
                                      _c.c_void_p, _c.c_void_p]),
@@ -308,6 +310,34 @@ class DeviceDict:
                                               _dev(row_bound, torch.float32, "row_bound").data_ptr() if row_bound is not None else None,
                                               _stream()))
         return feat, val, count, recon, scores
+
+    DECODE_SPARSE_MIN_ROWS = 256   # below this the dense matmul's launch is as cheap as the two sparse ones
+    DECODE_SPARSE_CAPACITY = 1024
+
+    def decode_dense_acts(self, acts: torch.Tensor) -> Optional[torch.Tensor]:
+        """``acts @ W_dec + out_bias`` for dense activations ``[..., d_sae]`` that are mostly zeros, as
+        ``tsc_dense_to_sparse`` + ``tsc_decode_sparse`` (one read of ``acts``, a gather of the active ``W_dec`` rows)
+        instead of the dense product.  Returns None when that is not worth it or not possible (few rows, a row with more
+        positives than the lists hold, values that are not plain activations): the caller multiplies densely then.
+        One host synchronisation (the capacity check)."""
+        a2 = acts.reshape(-1, self.d_sae)
+        m = a2.shape[0]
+        if m < self.DECODE_SPARSE_MIN_ROWS or not a2.is_cuda or a2.dtype != torch.float32 or not a2.is_contiguous() \
+                or len(self._keep) < 5:
+            return None
+        cap = min(self.DECODE_SPARSE_CAPACITY, self.d_sae)
+        feat = torch.empty(m, cap, dtype=torch.int32, device=a2.device)
+        val = torch.empty(m, cap, dtype=torch.float32, device=a2.device)
+        count = torch.empty(m, dtype=torch.int32, device=a2.device)
+        with torch.cuda.device(a2.device):
+            _check(lib().tsc_dense_to_sparse(a2.data_ptr(), m, self.d_sae, cap, feat.data_ptr(), val.data_ptr(),
+                                             count.data_ptr(), _stream()))
+        recon = self.decode_sparse(feat, val, count)  # queued before the check: the GPU does not wait for the host
+        # (a row with more positives than the lists hold, or with negative / NaN entries -- a hook may have edited the
+        # activations: reported as a negative count --: leave those to the matmul)
+        if bool(((count > cap) | (count < 0)).any()):
+            return None
+        return recon.reshape(*acts.shape[:-1], self.d_out)
 
     def decode_rows(self, feat: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
         """``val[i] * W_dec[feat[i]]`` -> ``[n, d_out]``."""

@@ -67,7 +67,9 @@ class ZSAE(HipDictionaryMixin, nn.Module):
     def forward(self, x, per_token=False):
         x = x.to(self.W_enc.device)
         acts = self.encode(x)
-        x_reconstruct = torch.matmul(acts, self.W_dec) + self.b_dec
+        x_reconstruct = self.device_dict().decode_dense_acts(acts) if not torch.is_grad_enabled() else None
+        if x_reconstruct is None:  # few rows (or an input the sparse decode does not take): the dense product
+            x_reconstruct = torch.matmul(acts, self.W_dec) + self.b_dec
         l2 = (x_reconstruct.float() - x.float()).pow(2).sum(-1)
         l1 = self.l1_coeff * acts.float().abs().sum(dim=-1)
         if not per_token:
