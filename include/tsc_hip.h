@@ -298,6 +298,10 @@ int tsc_contrib_scores_many(int n_dicts, const tsc_dict_t *const *dicts, int64_t
  */
 #define TSC_LENS_COUNT_IS_ZERO 1
 #define TSC_LENS_NO_SCREEN 2
+#define TSC_LENS_ROW_BOUNDS 16 /* screen_row_bound(s) point at 2 + 2 M floats: the two maxima, then every row's own pair
+                                 (bound[0], bound[1]) of the formula above taken without the max.  A candidate that passes
+                                 with the maxima is re-tested with its row's pair: rows shorter than the longest row of the
+                                 call get their own, tighter margin.  (Bounds the library computes always have this form.) */
 #define TSC_LENS_EMIT_ONLY 4 /* stop after the emit: feat/val/count hold the unordered emitted pairs (on a screening
                                 handle: the candidates); finish with tsc_sparse_lens_finish_many */
 int tsc_sparse_lens_pass(const tsc_dict_t *dict, const float *x, int64_t M, int max_active, int32_t *feat,

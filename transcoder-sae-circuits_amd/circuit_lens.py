@@ -328,7 +328,8 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
     device work behind the directions and the host time of preparing them hide under the emit kernel.
     ``screened``: use the handles that screen the emit with the bf16 MFMA and recompute the candidates exactly in
     fp32 (``TSC_F32_SCREEN``, include/tsc_hip.h) -- the same fp32 results, several times faster at CircuitLens sizes;
-    ``row_bounds [D, 2]`` are the screens' row bounds (``tsc_hip.screen_row_bound``), computed here when not given.
+    ``row_bounds [D, 2]`` or ``[D, 2 + 2 R]`` (with every row's own pair) are the screens' row bounds
+    (``tsc_hip.screen_row_bound``), computed here when not given.
     ``then(feat, val, count, recon, scores)``: optional device-only continuation, launched before the counts are
     read (its result is appended to the returned tuple).
     ``handle_cache``: a dict the caller keeps between passes over the SAME encoders and inputs.  With it the library
@@ -360,7 +361,7 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
             handle_cache[screened] = cached
     handles = cached["handles"]
     if screened and row_bounds is None:
-        row_bounds = torch.stack([tsc_hip.screen_row_bound(x, enc.b_dec.detach()) for enc, x in zip(encoders, inputs)])
+        row_bounds = torch.stack([tsc_hip.screen_row_bound(x, enc.b_dec.detach(), per_row=True) for enc, x in zip(encoders, inputs)])
     tail = None
     dirs_fn = dirs if callable(dirs) else None
     while True:
@@ -1013,7 +1014,8 @@ class BatchedCircuitLens:
 
             encs, xs = self._encoders_and_inputs()
             with torch.no_grad():
-                self._bounds = tsc_hip.screen_row_bound(torch.stack(xs), torch.stack([e.b_dec.detach() for e in encs]))
+                self._bounds = tsc_hip.screen_row_bound(torch.stack(xs), torch.stack([e.b_dec.detach() for e in encs]),
+                                                        per_row=True)
         return self._bounds
 
     def _tables(self):

@@ -115,7 +115,8 @@ int tsc_dict_create(tsc_dict_t **out, int d_in, int d_sae, int d_out, int comput
         if (compute_dtype != TSC_BF16 && d_in % 64 == 0)  // operand of the LDS-DMA kernel; other d_in use register staging
             e = hipMalloc((void **)&d->W_enc_t, (size_t)d_in * d_sae * sizeof(float));
         if (e == hipSuccess && compute_dtype == TSC_F32_SCREEN) e = hipMalloc((void **)&d->wnorm, (size_t)d_sae * 2 * sizeof(float));
-        if (e == hipSuccess && compute_dtype == TSC_F32_SCREEN) e = hipMalloc((void **)&d->screen_bound, 256);
+        if (e == hipSuccess && compute_dtype == TSC_F32_SCREEN)
+            e = hipMalloc((void **)&d->screen_bound, (size_t)(2 + 2 * TSC_BF16_WS_ROWS) * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&d->bias_fold, (size_t)d_sae * sizeof(float));
         int rc = e == hipSuccess ? tsc_dict_refresh(d, stream)
                                  : tsc_fail(TSC_ERR_HIP, "hipMalloc of the handle's derived operands failed: %s", hipGetErrorString(e));
@@ -347,13 +348,16 @@ int tsc_sparse_lens_pass(const tsc_dict_t *d, const float *x, int64_t M, int max
         // bf16 MFMA screen (16x the fp32 matrix rate) -> candidates; the finish kernel recomputes them exactly in fp32
         if (M > TSC_SCREEN_MAX_ROWS)
             return tsc_fail(TSC_ERR_UNSUPPORTED, "screened lens pass takes at most %d rows per call (got %lld)", TSC_SCREEN_MAX_ROWS, (long long)M);
+        bool per_row = (flags & TSC_LENS_ROW_BOUNDS) != 0;
         if (!screen_row_bound) {
             rc = tsc_launch_row_bound(x, M, d->d_in, d->b_dec, d->screen_bound, s);
             if (rc) return rc;
             screen_row_bound = d->screen_bound;
+            per_row = true;
         }
         a.screen_wnorm = d->wnorm;
         a.screen_bound = screen_row_bound;
+        a.screen_rows = per_row ? screen_row_bound + 2 : nullptr;
         rc = tsc_launch_encode_bf16(TSC_MODE_SPARSE, a, d->W_enc_bf16, d->x_bf16, s);
         if (rc || (flags & TSC_LENS_EMIT_ONLY)) return rc;
         return tsc_launch_sparse_finish(d->W_dec, d->out_bias, d->d_out, feat, val, count, M, max_active, dirs,
@@ -398,11 +402,14 @@ int tsc_sparse_lens_emit_many(int n_dicts, const tsc_dict_t *const *dicts, const
         for (int i = 0; i < n_dicts; ++i) {
             const tsc_dict_t *d = dicts[i];
             const float *bound = screen_row_bounds ? screen_row_bounds[i] : nullptr;
+            bool per_row = (flags & TSC_LENS_ROW_BOUNDS) != 0;
             if (!bound) {
                 rc = tsc_launch_row_bound(x[i], M, d->d_in, d->b_dec, d->screen_bound, s);
                 if (rc) return rc;
                 bound = d->screen_bound;
+                per_row = true;
             }
+            p[i].rows = per_row ? bound + 2 : nullptr;
             p[i].x_bf16 = d->x_bf16; p[i].W_bf16 = d->W_enc_bf16; p[i].b_enc = d->b_enc; p[i].wnorm = d->wnorm;
             p[i].bound = bound; p[i].feat = feat + (size_t)i * M * max_active; p[i].val = val + (size_t)i * M * max_active;
             p[i].count = count + (size_t)i * M; p[i].N = d->d_sae;

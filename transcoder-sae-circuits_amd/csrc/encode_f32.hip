@@ -441,6 +441,20 @@ __device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
                 }
             };
             auto emit = [&](int c, int bn, float v) {
+                if (BF16 && a.screen_rows) {
+                    // v carries the margin of the call's LONGEST row; this row's own margin is smaller by
+                    // (A_max - A_row) wnorm[n] + (B_max - B_row) wdiff[n] (row_bound_kernel): re-test with it.  Cold path:
+                    // only candidates of the loose test get here.
+                    const int n = n0 + cbase + bn * 32;
+                    const float2 rb = ((const float2 *)a.screen_rows)[m0 + rbase + c];
+                    const float amax = a.screen_bound[0], bmax = a.screen_bound[1];
+                    // (a call that holds an infinite row has infinite maxima: every pair is a candidate and stays one --
+                    // inf - inf would be NaN and dismiss them all)
+                    if (amax < __builtin_inff() && bmax < __builtin_inff()) {
+                        v -= (amax - rb.x) * a.screen_wnorm[n] + (bmax - rb.y) * a.screen_wnorm[a.N + n];
+                        if (!(v > sp_thr[bn])) return;
+                    }
+                }
                 int loc = ((rbase + c) << 8) | (cbase + bn * 32);
                 asm volatile("" : "+v"(loc));  // keep the arithmetic inside the (cold) branch
                 const int q = atomicAdd(&sm.sp_n[par], 1);
@@ -862,7 +876,7 @@ constexpr int GROUP_MAX = 32;
 struct EmitGroupArgs {
     struct One {
         const void *x, *Wt;                  // bf16(x - b_dec) [M][K] (the handle's staging), bf16(W_enc) transposed [N][K]
-        const float *bias, *wnorm, *bound;   // b_enc, column norms, the row bound of this call
+        const float *bias, *wnorm, *bound, *rows;  // b_enc, column norms, the row bounds of this call (maxima; per row or null)
         int *sp_feat, *sp_count;
         float *sp_val;
         int N, n_tiles_n, wg_end;            // wg_end: first workgroup of the NEXT problem
@@ -877,7 +891,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void encode_group_kernel(const EmitG
     const int wg0 = p ? g.d[p - 1].wg_end : 0;
     EncodeArgs a = {};
     a.x = (const float *)g.d[p].x; a.Wt = (const float *)g.d[p].Wt; a.bias = g.d[p].bias;
-    a.screen_wnorm = g.d[p].wnorm; a.screen_bound = g.d[p].bound;
+    a.screen_wnorm = g.d[p].wnorm; a.screen_bound = g.d[p].bound; a.screen_rows = g.d[p].rows;
     a.sp_feat = g.d[p].sp_feat; a.sp_val = g.d[p].sp_val; a.sp_count = g.d[p].sp_count;
     a.N = g.d[p].N; a.n_tiles_n = g.d[p].n_tiles_n;
     a.M = g.M; a.K = g.K; a.max_active = g.max_active; a.m_split = g.m_split;
@@ -1034,7 +1048,7 @@ int tsc_launch_emit_group(int n, const EmitGroupProblem *p, long long M, int K, 
         if ((unsigned long long)p[i].N * K * 2 + 8192ull >= (1ull << 32))
             return tsc_fail(TSC_ERR_UNSUPPORTED, "bf16 encode needs d_in * d_sae * 2 < 4 GiB");
         g.d[i].x = p[i].x_bf16; g.d[i].Wt = p[i].W_bf16; g.d[i].bias = p[i].b_enc; g.d[i].wnorm = p[i].wnorm;
-        g.d[i].bound = p[i].bound; g.d[i].sp_feat = p[i].feat; g.d[i].sp_val = p[i].val; g.d[i].sp_count = p[i].count;
+        g.d[i].bound = p[i].bound; g.d[i].rows = p[i].rows; g.d[i].sp_feat = p[i].feat; g.d[i].sp_val = p[i].val; g.d[i].sp_count = p[i].count;
         g.d[i].N = p[i].N; g.d[i].n_tiles_n = (p[i].N + C::BN - 1) / C::BN;
         total += (long long)g.d[i].n_tiles_n * g.m_split;
         g.d[i].wg_end = (int)total;

@@ -163,8 +163,13 @@ __global__ __launch_bounds__(256) void row_bound_kernel(const float *__restrict_
         }
         sd += (float)K * 1.2e-38f;  // squares that underflowed: each lost less than the smallest normal number
         const float nc = sqrtf(sc);
-        best0 = fmaxf(best0, (sqrtf(sd) + g * nc + g * (sqrtf(sr) + nb)) * 1.0001f);
-        best1 = fmaxf(best1, nc * 1.0001f);
+        const float r0 = (sqrtf(sd) + g * nc + g * (sqrtf(sr) + nb)) * 1.0001f, r1 = nc * 1.0001f;
+        if (lane == 0) {  // the row's own pair: the epilogue re-tests a candidate with it (EncodeArgs::screen_rows)
+            bound[2 + 2 * row] = r0;
+            bound[3 + 2 * row] = r1;
+        }
+        best0 = fmaxf(best0, r0);
+        best1 = fmaxf(best1, r1);
     }
     if (lane == 0) { wave_max[0][wave] = best0; wave_max[1][wave] = best1; }
     __syncthreads();
@@ -183,7 +188,7 @@ int tsc_launch_col_norms(const float *W, int K, int N, float *wnorm, hipStream_t
 }
 
 int tsc_launch_row_bound(const float *x, long long M, int K, const float *b_dec, float *bound, hipStream_t stream) {
-    TSC_HIP_CHECK(hipMemsetAsync(bound, 0, 2 * sizeof(float), stream));
+    TSC_HIP_CHECK(hipMemsetAsync(bound, 0, 2 * sizeof(float), stream));  // the maxima; the per-row pairs are all written
     long long blocks = (M + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(row_bound_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, M, K, b_dec, bound);
@@ -250,6 +255,7 @@ int tsc_launch_encode_bf16(int mode, const EncodeArgs &a, const void *W_bf16, vo
         c.M = rows;
         c.token_base = a.token_base + r0;
         if (a.out) c.out = a.out + r0 * a.N;
+        if (a.screen_rows) c.screen_rows = a.screen_rows + 2 * r0;
         if (a.sp_count) {
             c.sp_feat = a.sp_feat + r0 * a.max_active;
             c.sp_val = a.sp_val + r0 * a.max_active;

@@ -253,6 +253,7 @@ int tsc_launch_screen_topk(const tsc_dict *d, const float *x, long long M, long 
         a.m_split = n_slots;
         EncodeArgs s = a;  // K1: the screen
         s.screen_wnorm = d->wnorm; s.screen_bound = bound;
+        s.screen_rows = row_bound ? nullptr : bound + 2;  // the library's own bounds carry every row's pair
         s.sq_floor = floor; s.sq_entries = entries; s.sq_counters = counters; s.sq_overflow = overflow;
         EncodeArgs probe = s;
         probe.bf16 = 1;

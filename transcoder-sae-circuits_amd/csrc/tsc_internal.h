@@ -14,7 +14,8 @@ struct tsc_dict {
     void *x_bf16;                                           // owned (TSC_BF16 only): bf16(x - b_dec) of one chunk of rows
     float *bias_fold;                                       // owned: b_enc - b_dec @ W_enc (fp64 sums), [d_sae]
     float *wnorm;                                           // owned (TSC_F32_SCREEN only): [2][d_sae] column norms of the screen's margin (encode_operands.hip)
-    float *screen_bound;                                    // owned (TSC_F32_SCREEN only): two floats, the row bounds of the current call
+    float *screen_bound;                                    // owned (TSC_F32_SCREEN only): 2 + 2 * TSC_BF16_WS_ROWS floats, the row bounds of the current call:
+                                                            // the two maxima, then the pair of every row (row_bound_kernel)
 };
 
 // rows of a handle's bf16 staging buffer for x = rows per chunk of every bf16 / screened call (include/tsc_hip.h:
@@ -58,6 +59,9 @@ struct EncodeArgs {
     // |exact fp32 - bf16| for that column (row_bound_kernel, encode_operands.hip), so every
     // feature whose exact activation is positive is emitted as a candidate
     const float *screen_wnorm, *screen_bound;
+    // optional: the bound pair of every row of this launch [M][2]; a candidate that passes the test with the maxima is
+    // re-tested with its own row's pair before it is emitted (rows shorter than the longest one get a tighter margin)
+    const float *screen_rows;
     // bf16 SCREEN of the fused top-k (screen_topk.hip): SPARSE epilogue, but a pair is emitted when its screened value
     // reaches the feature's floor (k-th best over all slots), and it goes to the emitting workgroup's own queue
     // sq_entries[w * sq_cap ..] as (row in this launch << 8 | column in tile); a full queue raises *sq_overflow
@@ -70,7 +74,7 @@ struct EncodeArgs {
 int tsc_launch_encode_f32(int mode, const EncodeArgs &a, hipStream_t stream);  // a.m_split <= 0: balanced
 struct EmitGroupProblem {  // one dictionary of a grouped bf16 screen emit (encode_f32.hip: tsc_launch_emit_group)
     const void *x_bf16, *W_bf16;
-    const float *b_enc, *wnorm, *bound;
+    const float *b_enc, *wnorm, *bound, *rows;  // rows: per-row bound pairs [M][2] or null
     int *feat, *count;
     float *val;
     int N;
@@ -86,6 +90,7 @@ int tsc_launch_fold_bias(const float *W, const float *b_enc, const float *b_dec,
                          hipStream_t stream);
 int tsc_launch_encode_bf16(int mode, const EncodeArgs &a, const void *W_bf16, void *x_bf16, hipStream_t stream);
 int tsc_launch_col_norms(const float *W, int K, int N, float *wnorm, hipStream_t stream);
+// bound: 2 + 2 * M floats (maxima, then per-row pairs)
 int tsc_launch_row_bound(const float *x, long long M, int K, const float *b_dec, float *bound, hipStream_t stream);
 size_t tsc_bf16_workspace_bytes(int K);
 int tsc_pack_w_bf16(const float *W, int K, int N, void *dst, hipStream_t stream);

@@ -271,7 +271,8 @@ class DeviceDict:
         ``count.max()`` with ``feat.shape[1]`` once for as many dictionaries as it likes (``out`` may carry
         preallocated ``feat/val/count`` (and optionally ``recon/scores``) views -- ``count`` then has to be zero
         already -- so that one memset and one reduction serve a whole pass).  ``row_bound``: two-element device
-        tensor for a ``F32_SCREEN`` handle (see :func:`screen_row_bound`); None lets the library compute it;
+        tensor for a ``F32_SCREEN`` handle (see :func:`screen_row_bound`; ``2 + 2 M`` elements: with every row's own pair);
+        None lets the library compute it;
         ``screen=False`` asks such a handle for the plain fp32 emit.  ``emit_only``: stop after the emit
         (``TSC_LENS_EMIT_ONLY``); :func:`sparse_lens_finish_many` then finishes several dictionaries in one launch."""
         x2 = _dev(x, torch.float32, "x").reshape(-1, self.d_in)
@@ -304,7 +305,9 @@ class DeviceDict:
             dptr = dirs.data_ptr()
         with torch.cuda.device(dev):
             _check(lib().tsc_sparse_lens_pass(self._handle, x2.data_ptr(), m, cap, feat.data_ptr(), val.data_ptr(),
-                                              count.data_ptr(), zeroed | (0 if screen else 2) | (4 if emit_only else 0), dptr, stride,
+                                              count.data_ptr(),
+                                              zeroed | (0 if screen else 2) | (4 if emit_only else 0)
+                                              | (16 if row_bound is not None and row_bound.numel() == 2 + 2 * m else 0), dptr, stride,
                                               recon.data_ptr() if recon is not None else None,
                                               scores.data_ptr() if scores is not None else None,
                                               _dev(row_bound, torch.float32, "row_bound").data_ptr() if row_bound is not None else None,
@@ -457,17 +460,22 @@ class LensGroup:
             raise TscError("LensGroup.emit: stacked buffers do not match the dictionaries")
         rb = None
         if row_bounds is not None:
-            if tuple(row_bounds.shape) != (n, 2) or not row_bounds.is_contiguous() or row_bounds.dtype != torch.float32:
-                raise TscError("LensGroup.emit: row_bounds must be a contiguous float32 [n_dicts, 2] (screen_row_bound)")
+            width = row_bounds.shape[-1]
+            if row_bounds.dim() != 2 or row_bounds.shape[0] != n or width not in (2, 2 + 2 * M) \
+                    or not row_bounds.is_contiguous() or row_bounds.dtype != torch.float32:
+                raise TscError("LensGroup.emit: row_bounds must be a contiguous float32 [n_dicts, 2] or [n_dicts, 2 + 2 M] "
+                               "(screen_row_bound)")
             base = row_bounds.data_ptr()
-            if getattr(self, "_rb_base", None) != base:
-                self._rb, self._rb_base = (ctypes.c_void_p * n)(*range(base, base + 8 * n, 8)), base
+            if getattr(self, "_rb_base", None) != (base, width):
+                self._rb, self._rb_base = (ctypes.c_void_p * n)(*range(base, base + 4 * width * n, 4 * width)), (base, width)
             rb = self._rb
+            per_row_flag = 16 if width > 2 else 0
         st = [s.cuda_stream for s in streams] if streams else [_stream()]
         sa = (ctypes.c_void_p * len(st))(*st)
         with torch.cuda.device(self.device):
             _check(lib().tsc_sparse_lens_emit_many(n, self.hs, self.xs, M, cap, feat.data_ptr(), val.data_ptr(),
-                                                   count.data_ptr(), (1 if count_is_zero else 0) | (0 if screen else 2),
+                                                   count.data_ptr(),
+                                                   (1 if count_is_zero else 0) | (0 if screen else 2) | (per_row_flag if rb is not None else 0),
                                                    rb, sa, len(st)))
 
     def finish(self, feat, val, count, dirs=None, recon=None, scores=None, screen=True) -> None:
@@ -487,17 +495,22 @@ class LensGroup:
                                                      scores.data_ptr() if scores is not None else None, _stream()))
 
 
-def screen_row_bound(x: torch.Tensor, b_dec: torch.Tensor) -> torch.Tensor:
+def screen_row_bound(x: torch.Tensor, b_dec: torch.Tensor, per_row: bool = False) -> torch.Tensor:
     """The ``screen_row_bound`` of ``tsc_sparse_lens_pass`` (include/tsc_hip.h) for rows ``x [..., M, d_in]``: a device
     tensor ``[..., 2]``, with ``xc = x - b_dec``, ``g = 2 d_in 2^-24``:
     ``[max_m (||bf16(xc_m) - xc_m|| + g ||xc_m|| + g (||x_m|| + ||b_dec||)),  max_m ||xc_m||]``, rounded up.
-    Leading axes batch over dictionaries (``b_dec [..., d_in]``)."""
+    Leading axes batch over dictionaries (``b_dec [..., d_in]``).  ``per_row``: ``[..., 2 + 2 M]`` -- the maxima followed by
+    every row's own pair (``TSC_LENS_ROW_BOUNDS``: candidates are re-tested with their row's margin)."""
     g = 2.0 * x.shape[-1] * 2.0 ** -24
     xc = x - b_dec.unsqueeze(-2)
     err = (xc.to(torch.bfloat16).to(torch.float32) - xc).norm(dim=-1) + (x.shape[-1] * 1.2e-38) ** 0.5
     centred = xc.norm(dim=-1)
-    first = (err + g * centred + g * (x.norm(dim=-1) + b_dec.norm(dim=-1).unsqueeze(-1))).amax(dim=-1)
-    return (torch.stack([first, centred.amax(dim=-1)], dim=-1) * 1.0001).to(torch.float32).contiguous()
+    first = err + g * centred + g * (x.norm(dim=-1) + b_dec.norm(dim=-1).unsqueeze(-1))
+    maxima = torch.stack([first.amax(dim=-1), centred.amax(dim=-1)], dim=-1)
+    if per_row:
+        rows = torch.stack([first, centred], dim=-1).flatten(-2)                    # [..., 2 M]: (A_0, B_0, A_1, B_1, ...)
+        maxima = torch.cat([maxima, rows], dim=-1)
+    return (maxima * 1.0001).to(torch.float32).contiguous()
 
 
 def lens_assemble(head: torch.Tensor, aux: torch.Tensor, group_aux, scores: torch.Tensor, count: torch.Tensor,
