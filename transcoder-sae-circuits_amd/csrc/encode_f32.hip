@@ -82,6 +82,13 @@ struct __attribute__((aligned(16))) Smem {
     // SPARSE: the tile's positive activations, staged so that their global appends go out together
     float sp_val[LLDS ? 1 : SPQ];
     int sp_loc[LLDS ? 1 : SPQ];  // (row in tile << 8) | column in tile
+    // bf16 screen with per-row bounds (EncodeArgs::screen_rows): the bound pairs of the tile's rows (filled by LDS-DMA with
+    // the tile's first k-step), the two margin norms of the workgroup's columns, and the call's maxima.  Everything the
+    // re-test of a candidate needs sits in LDS: the k-loop runs at the register limit, and four more live registers
+    // spill (measured: the 24-dictionary emit 725 -> 917 us).
+    float2 rowb[LLDS ? 1 : C::BM];
+    float coln[2][LLDS ? 1 : C::BN];
+    float2 rbmax;
 };
 
 __device__ __forceinline__ bool ranks_below(float v, long long id, float w, long long wid) {
@@ -172,6 +179,12 @@ __device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
             be[bn] += a.screen_bound[0] * a.screen_wnorm[n] + a.screen_bound[1] * a.screen_wnorm[a.N + n] +
                       2.f * (float)a.K * 5.9604645e-8f * fabsf(be[bn]);
     }
+    // per-row bounds of the bf16 screen (wave-uniform).  Not with a single row (the DMA below moves two rows per lane) and
+    // not when a row of the call is not finite: the maxima are then infinite, every pair is a candidate and stays one
+    // (inf - inf would dismiss them all).
+    bool has_rb = false;
+    if (BF16 && MODE == TSC_MODE_SPARSE && DMA && a.screen_rows && a.M > 1)
+        has_rb = a.screen_bound[0] < __builtin_inff() && a.screen_bound[1] < __builtin_inff();
     // SPARSE: a value is emitted when it exceeds this (0 = every positive activation; the top-k screen: just below the
     // feature's floor, so that a value equal to the k-th best -- which a smaller token id may still outrank -- passes)
     float sp_thr[WNB];
@@ -441,19 +454,14 @@ __device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
                 }
             };
             auto emit = [&](int c, int bn, float v) {
-                if (BF16 && a.screen_rows) {
+                if (BF16 && has_rb) {
                     // v carries the margin of the call's LONGEST row; this row's own margin is smaller by
                     // (A_max - A_row) wnorm[n] + (B_max - B_row) wdiff[n] (row_bound_kernel): re-test with it.  Cold path:
-                    // only candidates of the loose test get here.
-                    const int n = n0 + cbase + bn * 32;
-                    const float2 rb = ((const float2 *)a.screen_rows)[m0 + rbase + c];
-                    const float amax = a.screen_bound[0], bmax = a.screen_bound[1];
-                    // (a call that holds an infinite row has infinite maxima: every pair is a candidate and stays one --
-                    // inf - inf would be NaN and dismiss them all)
-                    if (amax < __builtin_inff() && bmax < __builtin_inff()) {
-                        v -= (amax - rb.x) * a.screen_wnorm[n] + (bmax - rb.y) * a.screen_wnorm[a.N + n];
-                        if (!(v > sp_thr[bn])) return;
-                    }
+                    // only candidates of the loose test get here, and all it reads is LDS.
+                    const float2 rb = sm.rowb[rbase + c], mx = sm.rbmax;
+                    const int col = cbase + bn * 32;
+                    v -= (mx.x - rb.x) * sm.coln[0][col] + (mx.y - rb.y) * sm.coln[1][col];
+                    if (!(v > sp_thr[bn])) return;
                 }
                 int loc = ((rbase + c) << 8) | (cbase + bn * 32);
                 asm volatile("" : "+v"(loc));  // keep the arithmetic inside the (cold) branch
@@ -690,6 +698,14 @@ __device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
         }
     }
     if (MODE == TSC_MODE_SPARSE && tid == 0) sm.sp_n[0] = sm.sp_n[1] = 0;
+    if (BF16 && has_rb) {
+        if (tid < BN) {
+            const int n = n0 + tid < a.N ? n0 + tid : a.N - 1;
+            sm.coln[0][tid] = a.screen_wnorm[n];
+            sm.coln[1][tid] = a.screen_wnorm[a.N + n];
+        }
+        if (tid == 0) sm.rbmax = make_float2(a.screen_bound[0], a.screen_bound[1]);
+    }
     __syncthreads();
     Frag F, G;
     if (mt < n_mtiles) ldfrag(0, 0, F);
@@ -721,6 +737,14 @@ __device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
             const long long next_m0 = has_next ? (mt + a.m_split) * BM : m0;
             const char *xt = (const char *)a.x + (size_t)m0 * a.K * ES + 128;  // k-step 1 of this tile
             const char *wt = (const char *)a.Wt + 128;
+            if (BF16 && has_rb && wave < BM / 128) {
+                // the bound pairs of this tile's rows, two rows (16 bytes) per lane, straight into LDS; the first k-step's
+                // vmcnt(0) waits for them, the later k-steps' barriers publish them.  (Every wave has left the previous
+                // tile's scan, the only reader, behind its barrier.)  Rows past M read the last pairs: masked anyway.
+                long long r0 = m0 + wave * 128 + lane * 2;
+                if (r0 > a.M - 2) r0 = a.M - 2;
+                __builtin_amdgcn_global_load_lds((gptr_t)(a.screen_rows + 2 * r0), (lptr_t)&sm.rowb[wave * 128], 16, 0, 0);
+            }
             auto kstep = [&](auto par_) {
                 constexpr int PAR = decltype(par_)::value;
                 // keep the tile bases in scalar registers (saddr + 32-bit lane offset addressing);
