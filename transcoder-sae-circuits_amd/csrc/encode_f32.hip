@@ -40,7 +40,6 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDA = BK + 4;  // 144-byte rows: ds_read_b128 of 16 consecutive rows hits 16 distinct slots
 constexpr int QD = 4;   // candidate slots per feature and round
-constexpr int SPQ = 512;  // staged sparse entries per tile (more go straight to HBM)
 constexpr int KL = 20;  // list length up to which the lists' values are mirrored in LDS
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -52,6 +51,7 @@ struct Cfg {
     static constexpr int WMB = WMB_, WNB = WNB_, OCC = OCC_;  // 32x32 blocks per wave; workgroups per CU
     static constexpr int WVM = WVM_, WVN = WVN_, NW = WVM * WVN, NT = 64 * NW;  // waves as WVM x WVN
     static constexpr int BM = WVM * WMB * 32, BN = WVN * WNB * 32;
+    static constexpr int WQ = WMB * WNB * 32;  // SPARSE: entries a wave stages per round (1/32 of its elements)
     static constexpr int A_LD = BM * 8 / NT;                  // float4 loads of x per thread and k-step
     static constexpr int B_TPR = BN / 4;                      // threads per W row
     static constexpr int B_RPP = NT / B_TPR;                  // W rows per pass
@@ -62,32 +62,35 @@ struct Cfg {
 typedef Cfg<2, 2, 2, 2, 2> CfgSmall;  // 128x128, 4 waves of 64x64, two workgroups per CU
 typedef Cfg<4, 2, 2, 4, 1> CfgLarge;  // 256x256, 8 waves of 128x64, one workgroup per CU
 
-template <class C, bool DMA, bool LLDS>
+template <class C, int MODE, bool DMA, bool LLDS>
 struct __attribute__((aligned(16))) Smem {
+    static constexpr int TN = MODE == TSC_MODE_TOPK ? C::BN : 1;  // the per-feature state exists in the TOPK kernels only
+    static constexpr bool SP = MODE == TSC_MODE_SPARSE;
     float A[2][C::BM * (DMA ? BK : LDA)];  // register staging: padded rows; LDS-DMA: 32-float rows, 16-byte chunks XOR-swizzled
     float B[2][BK * C::BN];  // [k][n] image, read one dword per lane (32 consecutive n: conflict-free)
     float lv[LLDS ? C::BN * KL : 4];  // TOPK, k <= KL: the values of the workgroup's lists, [feature][KL]
-    float thr[C::BN];
-    float q_val[C::BN * QD];         // candidates of one round, [feature][QD]
-    unsigned char q_row[C::BN * QD];  // their rows in the tile
-    int f_nq[C::BN];                  // candidates pushed for the feature this round (may exceed QD)
+    float thr[TN];
+    float q_val[TN * QD];         // candidates of one round, [feature][QD]
+    unsigned char q_row[TN * QD];  // their rows in the tile
+    int f_nq[TN];                  // candidates pushed for the feature this round (may exceed QD)
     // per-feature list state, owned by thread t < BN: entries held, and the lowest-ranked entry
-    long long f_worst_id[C::BN];
-    float f_worst_v[C::BN];
-    unsigned char f_worst_pos[C::BN];  // k <= 64
-    unsigned char f_cnt[C::BN];
-    float f_floor[C::BN];  // k-th best of the feature over all slots when the launch started (0: unknown)
+    long long f_worst_id[TN];
+    float f_worst_v[TN];
+    unsigned char f_worst_pos[TN];  // k <= 64
+    unsigned char f_cnt[TN];
+    float f_floor[TN];  // k-th best of the feature over all slots when the launch started (0: unknown)
     int pushed, again;  // round flags: somebody pushed / somebody found its feature's slots full
-    int sp_n[2];        // SPARSE: entries staged in sp_val/sp_loc by the tile of this parity
-    // SPARSE: the tile's positive activations, staged so that their global appends go out together
-    float sp_val[LLDS ? 1 : SPQ];
-    int sp_loc[LLDS ? 1 : SPQ];  // (row in tile << 8) | column in tile
+    // SPARSE: every wave stages the entries of its part of the tile in a queue of its own (no atomics, no barrier: the
+    // wave that wrote a queue is the one that drains it), then issues their global appends together
+    float wq_val[SP ? C::NW : 1][SP ? C::WQ : 1];
+    int wq_loc[SP ? C::NW : 1][SP ? C::WQ : 1];  // (row in tile << 8) | column in tile
     // bf16 screen with per-row bounds (EncodeArgs::screen_rows): the bound pairs of the tile's rows (filled by LDS-DMA with
-    // the tile's first k-step), the two margin norms of the workgroup's columns, and the call's maxima.  Everything the
-    // re-test of a candidate needs sits in LDS: the k-loop runs at the register limit, and four more live registers
-    // spill (measured: the 24-dictionary emit 725 -> 917 us).
-    float2 rowb[LLDS ? 1 : C::BM];
-    float coln[2][LLDS ? 1 : C::BN];
+    // the tile's first k-step; two buffers, by tile parity: a wave may still drain the previous tile), the two margin norms
+    // and the emit threshold of the workgroup's columns, and the call's maxima.  Everything the re-test of a candidate
+    // needs sits in LDS: the k-loop runs at the register limit, and four more live registers spill (measured: the
+    // 24-dictionary emit 725 -> 917 us).
+    float2 rowb[2][SP && DMA ? C::BM : 1];
+    float coln[3][SP && DMA ? C::BN : 1];
     float2 rbmax;
 };
 
@@ -139,7 +142,7 @@ __device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
     constexpr int APW = BM / 8 / C::NW, BPW = BN / 8 / C::NW;  // 1-KiB DMA pieces per wave and k-step (x tile, W tile)
     static_assert(!DMA || KALIGNED, "DMA staging has no k tail handling");
     static_assert(!LLDS || (DMA && MODE == TSC_MODE_TOPK), "LDS lists belong to the fused top-k DMA kernel");
-    __shared__ Smem<C, DMA, LLDS> sm;
+    __shared__ Smem<C, MODE, DMA, LLDS> sm;
     if (MODE == TSC_MODE_TOPK && a.run_flag && *a.run_flag == 0) return;  // fallback launch of the screen: nothing overflowed
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -186,16 +189,16 @@ __device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
     if (BF16 && MODE == TSC_MODE_SPARSE && DMA && a.screen_rows && a.M > 1)
         has_rb = a.screen_bound[0] < __builtin_inff() && a.screen_bound[1] < __builtin_inff();
     // SPARSE: a value is emitted when it exceeds this (0 = every positive activation; the top-k screen: just below the
-    // feature's floor, so that a value equal to the k-th best -- which a smaller token id may still outrank -- passes)
+    // feature's floor, so that a value equal to the k-th best -- which a smaller token id may still outrank -- passes;
+    // columns past N: nothing exceeds +inf, so the scan needs no column predicate)
+    auto emit_threshold = [&](int n) -> float {
+        if (n >= a.N) return __builtin_inff();
+        const float fl = a.sq_floor ? a.sq_floor[n] : 0.f;
+        return fl > 0.f ? __uint_as_float(__float_as_uint(fl) - 1u) : 0.f;
+    };
     float sp_thr[WNB];
 #pragma unroll
-    for (int bn = 0; bn < WNB; ++bn) {
-        sp_thr[bn] = 0.f;
-        if (MODE == TSC_MODE_SPARSE && a.sq_floor && nok[bn]) {
-            const float fl = a.sq_floor[n0 + wn0 + bn * 32 + li];
-            sp_thr[bn] = fl > 0.f ? __uint_as_float(__float_as_uint(fl) - 1u) : 0.f;
-        }
-    }
+    for (int bn = 0; bn < WNB; ++bn) sp_thr[bn] = MODE == TSC_MODE_SPARSE ? emit_threshold(n0 + wn0 + bn * 32 + li) : 0.f;
 
     // TOPK: thread t < BN owns feature n0 + t of list set `slot`; its view of the list (kept in
     // LDS, not registers) is rebuilt from HBM at start-up
@@ -432,72 +435,92 @@ __device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
                 })
             }
         } else if (MODE == TSC_MODE_SPARSE) {
-            // append (feature, value) to the token's list; the emit is rare (a fraction of a percent of the
-            // elements), so the per-element cost is the test: interior tiles test the sign only
-            // Appending straight from the accumulator scan would serialise one global atomic round trip per
-            // element and lane.  Instead the tile's positives are staged in LDS (an LDS atomic each), and after
-            // one barrier every thread takes staged entries and issues their appends together: one round trip
-            // per tile.  The counter alternates with the tile parity, so its reset needs no second barrier.
+            // Append (feature, value) to the token's list.  A wave-level round trip per emitted element (an atomic on a
+            // shared counter, or the global append itself) costs far more than the scan: at the 0.3 % of a CircuitLens
+            // screen a fifth of the 128 per-lane elements have a candidate in SOME lane of the wave.  So the scan only
+            // stages: the position of an entry in the wave's own LDS queue is the wave's running count (a scalar) plus the
+            // lane's rank in the ballot, which needs no atomic and no wait.  The wave then drains its queue, one entry per
+            // lane, so the global appends of a tile go out together.  A queue holds 1/32 of the wave's elements; when more
+            // pass, the scan is repeated for the next window of the count -- whatever the data, nothing is dropped.
             const int par = ep_tiles & 1;
             ++ep_tiles;
-            auto direct = [&](long long row, int col, float v) {
-                if (a.sq_entries) {  // top-k screen: the workgroup's own candidate queue
-                    const int pos = atomicAdd(a.sq_counters + wg, 1);
-                    if (pos < a.sq_cap) a.sq_entries[(size_t)wg * a.sq_cap + pos] = ((unsigned)row << 8) | (unsigned)col;
-                    else *a.sq_overflow = 1;
-                    return;
-                }
-                const int pos = atomicAdd(a.sp_count + row, 1);
-                if (pos < a.max_active) {
-                    a.sp_feat[row * a.max_active + pos] = n0 + col;
-                    a.sp_val[row * a.max_active + pos] = v;
-                }
-            };
-            auto emit = [&](int c, int bn, float v) {
-                if (BF16 && has_rb) {
-                    // v carries the margin of the call's LONGEST row; this row's own margin is smaller by
-                    // (A_max - A_row) wnorm[n] + (B_max - B_row) wdiff[n] (row_bound_kernel): re-test with it.  Cold path:
-                    // only candidates of the loose test get here, and all it reads is LDS.
-                    const float2 rb = sm.rowb[rbase + c], mx = sm.rbmax;
-                    const int col = cbase + bn * 32;
-                    v -= (mx.x - rb.x) * sm.coln[0][col] + (mx.y - rb.y) * sm.coln[1][col];
-                    if (!(v > sp_thr[bn])) return;
-                }
-                int loc = ((rbase + c) << 8) | (cbase + bn * 32);
-                asm volatile("" : "+v"(loc));  // keep the arithmetic inside the (cold) branch
-                const int q = atomicAdd(&sm.sp_n[par], 1);
-                if (q < SPQ) {
-                    sm.sp_val[q] = v;
-                    sm.sp_loc[q] = loc;
-                } else {
-                    direct(m0 + (loc >> 8), loc & 255, v);
-                }
-            };
-            // block by block: the lane's largest value of a 32x32 block first (15 v_max, no branch), the 16
-            // per-element tests only where it passes -- a fraction of a percent of the elements are emitted
-            const bool interior = rows_left >= BM && n0 + BN <= a.N;
-#pragma unroll
-            for (int bm = 0; bm < WMB; ++bm)
+            constexpr int WQ = C::WQ;
+            float *qv = sm.wq_val[wave];
+            int *ql = sm.wq_loc[wave];
+            for (int win = 0;; win += WQ) {
+                int cnt = 0;  // wave-uniform: candidates of the elements scanned so far
+                // (opaque per window: otherwise hipcc hoists all 128 ballots out of the window loop and spills them)
+                float thr_w[WNB];
 #pragma unroll
                 for (int bn = 0; bn < WNB; ++bn) {
-                    float mx = acc[bm][bn][0];
+                    thr_w[bn] = sp_thr[bn];
+                    asm volatile("" : "+v"(thr_w[bn]));
+                }
+                int loc_w = (rbase << 8) | cbase;  // an entry's place in the tile: this plus a constant (cbase + bn * 32 < 256)
+                asm volatile("" : "+v"(loc_w));
 #pragma unroll
-                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[bm][bn][r]);
-                    if (mx > sp_thr[bn]) {
+                for (int bm = 0; bm < WMB; ++bm)
+#pragma unroll
+                    for (int bn = 0; bn < WNB; ++bn)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int c = bm * 32 + (r & 3) + 8 * (r >> 2);
                             const float v = acc[bm][bn][r];
-                            if (v > sp_thr[bn] && (interior || (nok[bn] && c < lim))) emit(c, bn, v);
+                            const bool p = v > thr_w[bn];
+                            const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
+                            if (m) {
+                                if (p) {
+                                    const unsigned q = (unsigned)(cnt - win) +
+                                                       __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                    if (q < (unsigned)WQ) {
+                                        qv[q] = v;
+                                        ql[q] = loc_w + (((bm * 32 + (r & 3) + 8 * (r >> 2)) << 8) | (bn * 32));
+                                    }
+                                }
+                                cnt += __builtin_popcountll(m);
+                            }
+                        }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int staged = cnt - win < WQ ? cnt - win : WQ;
+                for (int e0 = 0; e0 < staged; e0 += 64) {
+                    const int e = e0 + lane;
+                    bool live = e < staged;
+                    const int loc = live ? ql[e] : 0;
+                    float v = live ? qv[e] : 0.f;
+                    const int row = loc >> 8, col = loc & 255;
+                    live = live && m0 + row < a.M;  // rows past M are copies of the last row
+                    if (BF16 && has_rb && live && (m0 + row + 1 < a.M || !(a.M & 1))) {
+                        // v carries the margin of the call's LONGEST row; this row's own margin is smaller by
+                        // (A_max - A_row) wnorm[n] + (B_max - B_row) wdiff[n] (row_bound_kernel): re-test with it
+                        const float2 rb = sm.rowb[par][row], mx = sm.rbmax;
+                        v -= (mx.x - rb.x) * sm.coln[0][col] + (mx.y - rb.y) * sm.coln[1][col];
+                        live = v > sm.coln[2][col];
+                    }
+                    if (a.sq_entries) {  // top-k screen: the workgroup's own candidate queue, one reservation per wave
+                        const unsigned long long lm = __builtin_amdgcn_ballot_w64(live);
+                        if (lm) {
+                            int base = 0;
+                            if (lane == 0) base = atomicAdd(a.sq_counters + wg, __builtin_popcountll(lm));
+                            base = __builtin_amdgcn_readfirstlane(base);
+                            if (live) {
+                                const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u));
+                                if (pos < a.sq_cap) a.sq_entries[(size_t)wg * a.sq_cap + pos] = ((unsigned)(m0 + row) << 8) | (unsigned)col;
+                                else *a.sq_overflow = 1;
+                            }
+                        }
+                    } else if (live) {
+                        const long long grow = m0 + row;
+                        const int pos = atomicAdd(a.sp_count + grow, 1);
+                        if (pos < a.max_active) {
+                            a.sp_feat[grow * a.max_active + pos] = n0 + col;
+                            a.sp_val[grow * a.max_active + pos] = v;
                         }
                     }
                 }
-            __syncthreads();
-            const int staged = sm.sp_n[par] < SPQ ? sm.sp_n[par] : SPQ;
-            if (tid == 0) sm.sp_n[par ^ 1] = 0;  // last read before this tile's barrier
-            for (int e = tid; e < staged; e += NT) {
-                const int loc = sm.sp_loc[e];
-                direct(m0 + (loc >> 8), loc & 255, sm.sp_val[e]);
+                if (cnt <= win + WQ) break;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the drain's reads before the next window's writes
+                __builtin_amdgcn_wave_barrier();
             }
         } else {
             // Lane-local pre-check per 32x32 block: the lane's largest value of the block against
@@ -697,12 +720,12 @@ __device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
             sstore(0, 0);
         }
     }
-    if (MODE == TSC_MODE_SPARSE && tid == 0) sm.sp_n[0] = sm.sp_n[1] = 0;
     if (BF16 && has_rb) {
         if (tid < BN) {
             const int n = n0 + tid < a.N ? n0 + tid : a.N - 1;
             sm.coln[0][tid] = a.screen_wnorm[n];
             sm.coln[1][tid] = a.screen_wnorm[a.N + n];
+            sm.coln[2][tid] = emit_threshold(n0 + tid);
         }
         if (tid == 0) sm.rbmax = make_float2(a.screen_bound[0], a.screen_bound[1]);
     }
@@ -739,11 +762,13 @@ __device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
             const char *wt = (const char *)a.Wt + 128;
             if (BF16 && has_rb && wave < BM / 128) {
                 // the bound pairs of this tile's rows, two rows (16 bytes) per lane, straight into LDS; the first k-step's
-                // vmcnt(0) waits for them, the later k-steps' barriers publish them.  (Every wave has left the previous
-                // tile's scan, the only reader, behind its barrier.)  Rows past M read the last pairs: masked anyway.
+                // vmcnt(0) waits for them, the later k-steps' barriers publish them.  The buffer alternates with the tile
+                // parity: a slower wave may still drain the previous tile's queue (two tiles back it cannot: the k-loop's
+                // barriers lie in between).  Lanes past M - 2 read the last two rows: with an odd M the slot of row M - 1
+                // then holds row M - 2's pair, so the drain does not refine that row.
                 long long r0 = m0 + wave * 128 + lane * 2;
                 if (r0 > a.M - 2) r0 = a.M - 2;
-                __builtin_amdgcn_global_load_lds((gptr_t)(a.screen_rows + 2 * r0), (lptr_t)&sm.rowb[wave * 128], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(a.screen_rows + 2 * r0), (lptr_t)&sm.rowb[ep_tiles & 1][wave * 128], 16, 0, 0);
             }
             auto kstep = [&](auto par_) {
                 constexpr int PAR = decltype(par_)::value;
@@ -997,7 +1022,7 @@ int launch(EncodeArgs a, hipStream_t stream) {
     const bool dma = a.K % (2 * BK) == 0 && a.bias && a.Wt && fits32 && use_dma();
     const dim3 g((unsigned)grid), b(C::NT);
     // the mirror of the lists' values must fit in LDS next to the staging buffers of every resident workgroup
-    constexpr bool TK = MODE == TSC_MODE_TOPK && sizeof(Smem<C, true, true>) * C::OCC <= 160 * 1024;
+    constexpr bool TK = MODE == TSC_MODE_TOPK && sizeof(Smem<C, TSC_MODE_TOPK, true, true>) * C::OCC <= 160 * 1024;
     const bool lists = TK && a.topk <= KL && use_lds_lists();
     if (a.bf16) {
         if (a.K % 128 != 0 || !a.bias || !a.Wt) return tsc_fail(TSC_ERR_UNSUPPORTED, "bf16 encode needs d_in %% 128 == 0");
