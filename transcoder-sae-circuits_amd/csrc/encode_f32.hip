@@ -61,6 +61,8 @@ struct Cfg {
 };
 typedef Cfg<2, 2, 2, 2, 2> CfgSmall;  // 128x128, 4 waves of 64x64, two workgroups per CU
 typedef Cfg<4, 2, 2, 4, 1> CfgLarge;  // 256x256, 8 waves of 128x64, one workgroup per CU
+// (Cfg<4, 4, 2, 2, 1> -- four waves of 128x128, accumulators in AGPRs, a third less LDS fragment traffic per MFMA --
+// compiles to 640-700 spilled registers per lane with this body: hipcc keeps copies of the accumulators in VGPRs)
 
 template <class C, int MODE, bool DMA, bool LLDS>
 struct __attribute__((aligned(16))) Smem {
@@ -82,6 +84,8 @@ struct __attribute__((aligned(16))) Smem {
     int pushed, again;  // round flags: somebody pushed / somebody found its feature's slots full
     // SPARSE: every wave stages the entries of its part of the tile in a queue of its own (no atomics, no barrier: the
     // wave that wrote a queue is the one that drains it), then issues their global appends together
+    // (two arrays, two ds_write_b32: one 8-byte write wants value and place in a register PAIR, the value is an
+    // accumulator, and the pairing constraint spills 200 registers -- measured: emit 670 -> 1010 us)
     float wq_val[SP ? C::NW : 1][SP ? C::WQ : 1];
     int wq_loc[SP ? C::NW : 1][SP ? C::WQ : 1];  // (row in tile << 8) | column in tile
     // bf16 screen with per-row bounds (EncodeArgs::screen_rows): the bound pairs of the tile's rows (filled by LDS-DMA with
@@ -1091,6 +1095,8 @@ int tsc_launch_emit_group(int n, const EmitGroupProblem *p, long long M, int K, 
     memset(&g, 0, sizeof(g));
     const long long n_mtiles = (M + C::BM - 1) / C::BM;
     g.M = M; g.K = K; g.max_active = max_active; g.n = n;
+    // one workgroup per tile up to 8 token tiles: a workgroup that walks the token tiles of its column tile re-reads
+    // the W tile from the Infinity Cache each time (measured at 512 / 1024 rows: 745 / 1368 us against 683 / 1165)
     g.m_split = (int)(n_mtiles < 8 ? n_mtiles : 8);
     long long total = 0;
     for (int i = 0; i < n; ++i) {
