@@ -266,6 +266,50 @@ def test_batched_circuit_lens_equals_single_prompt_lenses():
         te.batched_lens().lens(0).get_active_features(0)  # position not covered by an eval-position pass
 
 
+
+def test_direction_lens_with_the_decoders_folded_through_w_o_equals_the_z_space_form():
+    """``BatchedCircuitLens.direction_lens`` scores residual directions with the z-SAE decoders folded through W_O once
+    (``_ResidualSpaceZ``: no per-pass ``W_O @ d``).  Same contributions as the z-space form (the reference's order:
+    project the z vectors, then dot, src/circuit_lens.py:618-627) to the reference's tolerance, same winners up to
+    near-ties; a parameter of a z-SAE updated in place is picked up (the folded decoder is rebuilt)."""
+    from circuit_lens import BatchedCircuitLens
+
+    g5, *_, prompts = gi.g5_inputs()
+    _lens_world()
+    texts = [p["text"] for p in prompts[:8]]
+    dirs = torch.randn(len(texts), 768, generator=torch.Generator().manual_seed(11)).to(DEV)
+
+    def run(residual, positions):
+        batch = BatchedCircuitLens(texts, positions=positions)
+        batch.RESIDUAL_DECODER = residual
+        return batch, batch.direction_lens(dirs, k=10)
+
+    for positions in (-1, "all"):
+        b1, folded = run(True, positions)
+        b0, zspace = run(False, positions)
+        assert torch.equal(folded["mask"], zspace["mask"])
+        _close(folded["activations"], zspace["activations"], atol=ATOL)
+        _close(folded["top_values"], zspace["top_values"], atol=ATOL)
+        for r in range(folded["top_feature"].shape[0]):
+            mism = (folded["top_feature"][r] != zspace["top_feature"][r]).nonzero().flatten().tolist()
+            assert len(mism) <= 2
+            _assert_mismatches_are_near_ties(mism, zspace["top_values"][r].tolist() + [float("-inf")])
+        # the per-prompt views of the SAME batch still see z-space reconstructions (their own pass)
+        af = b1.lens(2).get_active_features(-1)
+        ref = b0.lens(2).get_active_features(-1)
+        _close(af.vectors, ref.vectors, atol=ATOL)
+    z = b1.z_saes[1]
+    before = b1.direction_lens(dirs, k=10)["activations"].clone()
+    with torch.no_grad():
+        z.W_dec.mul_(1.5)                                   # in place: the fold must be redone
+    after = b1.direction_lens(dirs, k=10)
+    b0.RESIDUAL_DECODER = False
+    want = b0.direction_lens(dirs, k=10)
+    assert not torch.allclose(after["activations"], before, atol=ATOL)
+    _close(after["activations"], want["activations"], atol=ATOL)
+    with torch.no_grad():
+        z.W_dec.div_(1.5)
+
 def test_batched_lens_revalidates_its_cached_handles():
     """``BatchedCircuitLens`` reuses the library handles and call tables of its first pass without checking them on
     the way in (the check runs while the GPU works).  A parameter updated in place, or re-allocated, between two

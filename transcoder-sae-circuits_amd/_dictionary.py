@@ -32,7 +32,7 @@ class HipDictionaryMixin:
     def _out_bias(self) -> torch.Tensor:  # pragma: no cover - overridden
         raise NotImplementedError
 
-    _HANDLE_ATTRS = ("_hip", "_hip_bf16", "_hip_screen", "_projectors")
+    _HANDLE_ATTRS = ("_hip", "_hip_bf16", "_hip_screen", "_projectors", "_resid_adapter")
 
     def __getstate__(self):
         """Library handles (ctypes pointers into this process' GPU context) never travel with a copy or a pickle:

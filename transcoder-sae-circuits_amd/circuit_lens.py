@@ -294,6 +294,74 @@ class _PromptCacheView:
         return t[self._i:self._i + 1, :self._n]
 
 
+class _ResidualSpaceZ:
+    """A z-SAE as the direction lens sees it: the same encoder, its decoder expressed in the residual stream --
+    ``W_dec @ W_O[layer]`` rows and ``b_dec @ W_O[layer]`` -- so that a feature's contribution to a residual direction
+    ``d`` is ``act x (W_dec W_O)[f] . d`` and nothing of the pass depends on ``W_O @ d``: the reference projects every
+    z vector through W_O before it is scored (src/circuit_lens.py:618-627); folding W_O into the decoder ONCE replaces
+    the per-pass pull-back of the directions (a [R, 768] x [768, 768] product per layer).  Quacks like the encoder for
+    ``run_dictionary_pass`` (``device_dict``, ``W_dec``, ``b_dec``).  The library handle and the folded decoder are
+    rebuilt when a parameter of the z-SAE is re-allocated or updated in place, or when W_O changes."""
+
+    def __init__(self, z_sae, w_o_flat: torch.Tensor):
+        self.z_sae = z_sae
+        self._w_o = w_o_flat              # [n_heads * d_head, d_model]
+        self._w_o_version = w_o_flat._version
+        self._handles: dict = {}          # screened -> (key, tsc_hip.DeviceDict)
+        self._folded = None               # (key, W_dec W_O, b_dec W_O)
+
+    def same_projection(self, w_o_flat: torch.Tensor) -> bool:
+        """Is this the projection the adapter was made for?  (Asked once per batch.  Same storage: yes -- an in-place
+        update shows in the version the handle key carries; other storage, e.g. a property that stacks W_O anew on
+        every access: compare the values.)"""
+        w = self._w_o
+        if w.shape != w_o_flat.shape:
+            return False
+        return w.data_ptr() == w_o_flat.data_ptr() or bool(torch.equal(w, w_o_flat))
+
+    def _key(self):
+        z = self.z_sae
+        return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (z.W_enc, z.b_enc, z.b_dec, z.W_dec, self._w_o))
+
+    def _fold(self, key):
+        if self._folded is None or self._folded[0] != key:
+            z = self.z_sae
+            with torch.no_grad():
+                self._folded = (key, torch.matmul(z.W_dec.detach(), self._w_o).contiguous(),
+                                torch.mv(self._w_o.t(), z.b_dec.detach()).contiguous())
+        return self._folded[1], self._folded[2]
+
+    @property
+    def W_dec(self) -> torch.Tensor:
+        return self._fold(self._key())[0]
+
+    @property
+    def b_dec(self) -> torch.Tensor:  # the ENCODER's input bias (row bounds of the screen): unchanged
+        return self.z_sae.b_dec
+
+    @property
+    def b_out(self) -> torch.Tensor:  # what the reconstruction adds: b_dec W_O
+        return self._fold(self._key())[1]
+
+    def device_dict(self, bf16: bool = False, screened: bool = False):
+        import tsc_hip
+
+        z = self.z_sae
+        if screened and (bf16 or z.W_enc.shape[0] % 128 != 0 or z.W_enc.shape[0] > 768 or self._w_o.shape[1] > 768):
+            screened = False
+        key = self._key()
+        cur = self._handles.get(screened)
+        if cur is None or cur[0] != key:
+            z._require_gpu_fp32()
+            W_r, b_r = self._fold(key)
+            if cur is not None:
+                cur[1].close()
+            h = tsc_hip.DeviceDict(z.W_enc.detach().contiguous(), z.b_enc.detach().contiguous(), z.b_dec.detach().contiguous(),
+                                   W_r, b_r, compute_dtype=tsc_hip.F32_SCREEN if screened else tsc_hip.F32)
+            cur = self._handles[screened] = (key, h)
+        return cur[1]
+
+
 _PASS_STREAMS: Dict[str, list] = {}
 
 
@@ -344,7 +412,6 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
     n_d = len(encoders)
     rows = inputs[0].shape[0]
     dev = inputs[0].device
-    d_out = encoders[0].W_dec.shape[1]
     cap = max(1, min(int(max_active), tsc_hip.LENS_PASS_MAX_ACTIVE))
     screened = screened and rows <= tsc_hip.SCREEN_MAX_ROWS
 
@@ -356,7 +423,7 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
     unvalidated = cached is not None
     if cached is None:
         handles, versions = look_up()
-        cached = {"handles": handles, "versions": versions, "group": None}
+        cached = {"handles": handles, "versions": versions, "group": None, "plan": None}
         if handle_cache is not None:
             handle_cache[screened] = cached
     handles = cached["handles"]
@@ -365,24 +432,34 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
     tail = None
     dirs_fn = dirs if callable(dirs) else None
     while True:
+        # Everything between here and the emit's launch is host time with the GPU idle: the shape of the pass (which
+        # calls, which streams) is decided once per set of handles, and only the emit's own buffers are allocated
+        # before it is queued.
+        plan = cached.get("plan")
+        if plan is None or plan[0] != (rows, n_d):
+            # The dictionaries are independent and, at CircuitLens sizes, each one's two launches are too short to fill
+            # the chip: with several dictionaries, stop each after its emit and finish them all in ONE launch
+            # (tsc_sparse_lens_finish_many): one dictionary's 512 rows are two workgroups per CU, 24 x 512 fill the chip.
+            grouped = 1 < n_d <= 32 and rows <= 8192 and len({(h.compute_dtype, h.d_in, h.d_out) for h in handles}) == 1 and \
+                len({id(h) for h in handles}) == n_d and os.environ.get("TSC_LENS_GROUPED", "1") != "0"
+            n_side = int(os.environ.get("TSC_LENS_STREAMS", "4"))  # 1: everything on the current stream (profiling)
+            # (the grouped screened emit is one launch on the current stream: no side streams, no cross-stream events)
+            one_launch = grouped and screened and handles[0].compute_dtype == tsc_hip.F32_SCREEN
+            use_side = rows <= 8192 and n_d > 1 and n_side > 1 and not one_launch
+            plan = cached["plan"] = ((rows, n_d), grouped, one_launch, use_side, n_side, handles[0].d_out)
+        _, grouped, one_launch, use_side, n_side, d_out = plan
         feat = torch.empty(n_d, rows, cap, dtype=torch.int32, device=dev)
         val = torch.empty(n_d, rows, cap, dtype=torch.float32, device=dev)
-        count = torch.zeros(n_d, rows, dtype=torch.int32, device=dev)
-        recon = torch.empty(n_d, rows, d_out, dtype=torch.float32, device=dev) if want_recon else None
-        scores = torch.empty(n_d, rows, cap, dtype=torch.float32, device=dev) if dirs is not None else None
-        # The dictionaries are independent and, at CircuitLens sizes, each one's two launches are too short to fill
-        # the chip (a 512-row emit is 8 us of bf16 MFMA work in a 43-us launch): spread them over a few HIP streams.
-        # Every buffer was allocated on the calling stream and outlives the pass; the side streams start after the
+        # (the grouped emit call zeroes the counts itself: one memset queued by the library, no torch launch)
+        count = torch.empty(n_d, rows, dtype=torch.int32, device=dev) if grouped else torch.zeros(n_d, rows, dtype=torch.int32, device=dev)
+        recon = scores = None
+        if not grouped:
+            recon = torch.empty(n_d, rows, d_out, dtype=torch.float32, device=dev) if want_recon else None
+            scores = torch.empty(n_d, rows, cap, dtype=torch.float32, device=dev) if dirs is not None else None
+        # Every buffer is allocated on the calling stream and outlives the pass; the side streams start after the
         # calling stream's work so far and the calling stream waits for all of them before the counts are read.
         main = torch.cuda.current_stream(dev)
-        # ... and, with several dictionaries, stop each after its emit and finish them all in ONE launch
-        # (tsc_sparse_lens_finish_many): one dictionary's 512 rows are two workgroups per CU, 24 x 512 fill the chip.
-        grouped = 1 < n_d <= 32 and rows <= 8192 and len({(h.compute_dtype, h.d_in, h.d_out) for h in handles}) == 1 and \
-            len({id(h) for h in handles}) == n_d and os.environ.get("TSC_LENS_GROUPED", "1") != "0"
-        n_side = int(os.environ.get("TSC_LENS_STREAMS", "4"))  # 1: everything on the current stream (profiling)
-        # (the grouped emit is one launch on the current stream: no side streams, no cross-stream events to queue)
-        one_launch = grouped and screened and handles[0].compute_dtype == tsc_hip.F32_SCREEN
-        side = _pass_streams(dev, n_side) if rows <= 8192 and n_d > 1 and n_side > 1 and not one_launch else []
+        side = _pass_streams(dev, n_side) if use_side else []
         _mark("pass: buffers ready")
         if side:
             start = torch.cuda.Event()
@@ -397,7 +474,10 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
                 group = cached["group"] = tsc_hip.LensGroup(handles, inputs)
             group.emit(feat, val, count, screen=screened,
                        row_bounds=row_bounds if screened and handles[0].compute_dtype == tsc_hip.F32_SCREEN else None,
-                       streams=side or None)
+                       streams=side or None, count_is_zero=False)
+            # (allocated while the emit runs)
+            recon = torch.empty(n_d, rows, d_out, dtype=torch.float32, device=dev) if want_recon else None
+            scores = torch.empty(n_d, rows, cap, dtype=torch.float32, device=dev) if dirs is not None else None
         for i, (h, x) in enumerate(zip(handles, inputs) if not grouped else ()):
             stream = side[i % len(side)] if side else main
             if side and i < len(side):
@@ -427,10 +507,12 @@ def run_dictionary_pass(encoders, inputs, max_active: int = 512, dirs=None, want
             fresh, versions = look_up()
             # (a refresh -- in-place parameter update -- replaces the handle's version tuple)
             if any(f is not h for f, h in zip(fresh, handles)) or any(v is not w for v, w in zip(versions, cached["versions"])):
-                cached.update(handles=fresh, versions=versions, group=None)
+                cached.update(handles=fresh, versions=versions, group=None, plan=None)
                 handles = fresh
                 continue  # the pass ran on handles of older parameters: again, with the current ones
-        counts_host = count.cpu()  # the one synchronisation of the pass
+        # the one synchronisation of the pass (a pinned buffer + non-blocking copy + stream synchronise measured slower
+        # than this blocking copy: 57 against 34 us from the tail's last launch to the return)
+        counts_host = count.cpu()
         _mark("pass: counts on host")
         worst = int(counts_host.max()) if counts_host.numel() else 0
         if worst <= cap:
@@ -1034,6 +1116,29 @@ class BatchedCircuitLens:
             }
         return self._tab
 
+    # The direction lens scores residual-stream directions: with the z-SAE decoders folded through W_O once
+    # (_ResidualSpaceZ) no pass pulls its directions back through W_O.  TSC_LENS_RESIDUAL=0: the z-space form
+    # (W_O @ d per pass, the z-SAEs' own handles).
+    RESIDUAL_DECODER = os.environ.get("TSC_LENS_RESIDUAL", "1") != "0"
+
+    def _residual_world(self):
+        """``(encoders, z W_O [L, R, d_model])``: the dictionaries of the pass with every z-SAE seen through W_O, and
+        the attention outputs the z-SAEs reconstruct (without b_O), projected once per batch."""
+        if getattr(self, "_resid", None) is None:
+            _, xs = self._encoders_and_inputs()
+            encs = []
+            with torch.no_grad():
+                for layer in range(self.model.cfg.n_layers):
+                    z, w = self.z_saes[layer], self._w_o_flat(layer)
+                    adapter = z.__dict__.get("_resid_adapter")
+                    if adapter is None or not adapter.same_projection(w):
+                        adapter = _ResidualSpaceZ(z, w)
+                        object.__setattr__(z, "_resid_adapter", adapter)
+                    encs += [adapter, self.mlp_transcoders[layer]]
+                z_resid = torch.stack([xs[2 * l] @ self._w_o_flat(l) for l in range(self.model.cfg.n_layers)])
+            self._resid = (encs, z_resid)
+        return self._resid
+
     def dictionary_pass(self, directions: Optional[torch.Tensor] = None):
         """Run (or return the cached) pass.  With ``directions`` (``[R, d_model]``, ``[n_prompts, d_model]`` with
         one row per prompt, or ``[d_model]``) the contribution scores are computed in the same launches; the
@@ -1107,10 +1212,17 @@ class BatchedCircuitLens:
         _mark("lens: start")
         d = self._row_directions(directions)
         encs, xs = self._encoders_and_inputs()
+        residual = self.RESIDUAL_DECODER and self.model.cfg.d_model == d.shape[1]
         with torch.no_grad():
             t = self._tables()
             n_layers, rows = self.model.cfg.n_layers, self.n_rows
             state = {}
+            if residual:
+                encs, z_resid = self._residual_world()
+                cache = self.__dict__.setdefault("_handle_cache_resid", {})
+                same = state["dirs"] = [d] * len(encs)  # every dictionary decodes into the residual stream: one direction
+            else:
+                cache = self._handle_cache
 
             def dirs_after_emit():
                 # queued behind the emits, which do not need them: the pull-back through W_O and its host time are hidden
@@ -1124,16 +1236,19 @@ class BatchedCircuitLens:
                 # z bias | transcoder error, transcoder bias), each dotted with the row's direction: ONE launch
                 head = torch.empty(rows, 2, dtype=torch.float32, device=d.device)
                 aux = torch.empty(rows, 5 * n_layers, dtype=torch.float32, device=d.device)
-                self._aux_dots(d, state["dz"], recon, head, aux)
+                if residual:
+                    self._aux_dots_residual(d, z_resid, encs, recon, head, aux)
+                else:
+                    self._aux_dots(d, state["dz"], recon, head, aux)
                 res = tsc_hip.lens_assemble(head, aux, [3, 2] * n_layers, scores, count, k=k, dense=dense,
                                             column_tags=self._column_tags(d.device), feat=feat)
                 res["top_info_long"] = res["top_info"].long()  # (queued here: nothing is launched after the host sync)
                 return res
 
             feat, val, count, recon, scores, counts_host, res = run_dictionary_pass(
-                encs, xs, self.max_active, dirs=dirs_after_emit, screened=self.screened, row_bounds=self._row_bounds(),
-                then=tail, handle_cache=self._handle_cache)
-            if self._pass is None:
+                encs, xs, self.max_active, dirs=same if residual else dirs_after_emit, screened=self.screened,
+                row_bounds=self._row_bounds(), then=tail, handle_cache=cache)
+            if self._pass is None and not residual:  # (the residual form's z reconstructions are not the z-space ones)
                 self._pass = (feat, val, count, recon, scores, counts_host)
             _mark("lens: pass returned")
             info = res["top_info_long"]  # [R, k, 4]: column, component, layer, feature (-1 where a row ran out)
@@ -1180,6 +1295,44 @@ class BatchedCircuitLens:
                 j = 2 + 5 * l
                 b[j] = b[j + 3] = b[j + 4] = dp
                 b[j + 1] = b[j + 2] = zp + l * zl
+                c[j + 1], c[j + 3] = rp + 2 * l * rl, rp + (2 * l + 1) * rl
+                o = ap + 20 * l
+                out[j], out[j + 1], out[j + 2], out[j + 3], out[j + 4] = o, o + 4, o + 8, o + 12, o + 16
+        tab.run(d.device)
+
+    def _aux_dots_residual(self, d, z_resid, encs, recon, head, aux) -> None:
+        """``_aux_dots`` with the z-SAEs in residual space: z error = ``(z W_O - reconstruction) . d`` (the reconstruction
+        of a ``_ResidualSpaceZ`` handle already lies in the residual stream and carries ``b_dec W_O``), z bias =
+        ``(b_dec W_O) . d``; every term meets the row's direction itself."""
+        import tsc_hip
+
+        t = self._tables()
+        n_layers, rows, dm = self.model.cfg.n_layers, self.n_rows, d.shape[1]
+        tab = getattr(self, "_rd_resid", None)
+        if tab is None:
+            tab = tsc_hip.RowDotTable(2 + 5 * n_layers, rows, dm)
+            tab.set(0, t["embed"], None, d, head[:, 0])
+            tab.set(1, t["pos_embed"], None, d, head[:, 1])
+            for l in range(n_layers):
+                j = 2 + 5 * l
+                tab.set(j, t["b_o"][l], None, d, aux[:, 5 * l])
+                tab.set(j + 1, z_resid[l], recon[2 * l], d, aux[:, 5 * l + 1])
+                tab.set(j + 2, encs[2 * l].b_out, None, d, aux[:, 5 * l + 2])
+                tab.set(j + 3, t["mlp_out"][l], recon[2 * l + 1], d, aux[:, 5 * l + 3])
+                tab.set(j + 4, t["t_b_out"][l], None, d, aux[:, 5 * l + 4])
+            self._rd_resid = tab
+        else:  # same shapes and strides as when the table was made: only base addresses move
+            if not (d.is_contiguous() and recon.is_contiguous()):
+                raise tsc_hip.TscError("direction lens: directions / reconstructions must be contiguous")
+            dp, rp, hp, ap = d.data_ptr(), recon.data_ptr(), head.data_ptr(), aux.data_ptr()
+            rl = recon.stride(0) * 4
+            a, b, c, out = tab.a, tab.b, tab.c, tab.out
+            b[0] = b[1] = dp
+            out[0], out[1] = hp, hp + 4
+            for l in range(n_layers):
+                j = 2 + 5 * l
+                b[j] = b[j + 1] = b[j + 2] = b[j + 3] = b[j + 4] = dp
+                a[j + 2] = encs[2 * l].b_out.data_ptr()  # (refolded when a parameter of the z-SAE changed)
                 c[j + 1], c[j + 3] = rp + 2 * l * rl, rp + (2 * l + 1) * rl
                 o = ap + 20 * l
                 out[j], out[j + 1], out[j + 2], out[j + 3], out[j + 4] = o, o + 4, o + 8, o + 12, o + 16

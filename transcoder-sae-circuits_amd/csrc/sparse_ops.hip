@@ -634,11 +634,11 @@ __global__ __launch_bounds__(256) void lens_assemble_kernel(const AssembleArgs p
             for (int u = 0; u < 8; ++u) {
                 const int g = g0 + u < p.n_groups ? g0 + u : p.n_groups - 1;
                 live[u] = slot < s_cnt[g];
-                v[u] = sc[g * gstride + slot];
+                v[u] = live[u] ? sc[g * gstride + slot] : 0.f;  // (dead slots are not read: 6 of 7 at CircuitLens densities)
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (g0 + u < p.n_groups) put(p.col_off[g0 + u] + p.aux_n[g0 + u] + slot, live[u] ? v[u] : 0.f, live[u]);
+                if (g0 + u < p.n_groups) put(p.col_off[g0 + u] + p.aux_n[g0 + u] + slot, v[u], live[u]);
         }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
@@ -790,8 +790,8 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const RowDotArgs p) {
     const long long r = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunks = p.d >> 2;
-    // (few rows -- a single-position lens query -- spread the terms over gridDim.y workgroups: one row's 62 dot products
-    // on one workgroup are a chain of 16 dependent round trips)
+    // (the terms are spread over gridDim.y workgroups: one row's 62 dot products on one workgroup are a chain of 16
+    // dependent round trips)
     for (int j = blockIdx.y * 4 + wave; j < p.n; j += 4 * gridDim.y) {  // j is wave-uniform: the term's fields are scalar loads
         const RowDotArgs::Term &t = p.t[j];
         const f32x4 *a = (const f32x4 *)(t.a + r * t.sa), *b = (const f32x4 *)(t.b + r * t.sb);
@@ -1054,7 +1054,11 @@ int tsc_launch_rowdot_many(int n, const float *const *a, const long long *sa, co
             t.a = a[j0 + j]; t.b = b[j0 + j]; t.c = c ? c[j0 + j] : nullptr; t.out = out[j0 + j];
             t.sa = (int)sa[j0 + j]; t.sb = (int)sb[j0 + j]; t.sc = c && sc ? (int)sc[j0 + j] : 0; t.so = (int)so[j0 + j];
         }
-        const unsigned split = R >= 256 ? 1u : (unsigned)((p.n + 3) / 4);
+        // a workgroup walks its share of the terms one dependent round trip after the other: spread the terms over
+        // gridDim.y until about 4096 workgroups (two rounds of resident ones) are in flight
+        unsigned split = (unsigned)((4096 + R - 1) / R);
+        if (split > (unsigned)((p.n + 3) / 4)) split = (unsigned)((p.n + 3) / 4);
+        if (split < 1) split = 1;
         hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)R, split), dim3(256), 0, stream, p);
         TSC_HIP_CHECK(hipGetLastError());
     }
