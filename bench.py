@@ -271,12 +271,12 @@ def screened_topk_side_object(engine, dicts, widths, xs, n_batches, B, K, W, k, 
 
 
 # ----------------------------------------------------------------------------- config 4 (side object)
-def config4_side_object(device, n_prompts=512, reps=5):
+def config4_side_object(device, n_prompts=512, reps=10):
     """BASELINE configs[3], driver-timed as a side object of the same JSON line: the CircuitLens feature-contribution
     decomposition of ``n_prompts`` IOI-shaped prompts at the evaluation position, all 12 layers (12 transcoders + 12
     z-SAEs at their real widths), each prompt against its own logit-difference direction, through the PRODUCT path
-    (``TaskEvaluation.contribution_decomposition`` -> ``BatchedCircuitLens.direction_lens`` -> one
-    ``tsc_sparse_lens_pass`` per dictionary).  The stand-in model's forward is upstream of the path and timed
+    (``TaskEvaluation.contribution_decomposition`` -> ``BatchedCircuitLens.direction_lens`` -> the grouped emit and
+    finish of all 24 dictionaries, ``tsc_rowdot_many``, ``tsc_lens_assemble``; three untimed passes, then ``reps``).  The stand-in model's forward is upstream of the path and timed
     separately.  Bound at 512 positions: the fp32 MFMA contraction of the sparse emit (weights are read once:
     2 x 26 x 75.5 MB = 0.5 ms at 8 TB/s, against 3.2 ms of MFMA work at peak)."""
     import load_model_and_encoders as lme
@@ -317,8 +317,10 @@ def config4_side_object(device, n_prompts=512, reps=5):
         for enc, x in zip(*batch._encoders_and_inputs()):
             enc.b_enc.fill_(-2.8 * float((x[:128] @ enc.W_enc).std()))
         dirs = te.logit_difference_directions()
-        out = batch.direction_lens(dirs, k=10)  # warm-up (registers the dictionaries with the library)
+        for _ in range(3):  # warm-up (the first registers the dictionaries with the library and folds W_O into the z decoders)
+            out = batch.direction_lens(dirs, k=10)
         torch.cuda.synchronize()
+
         def timed_pass(b):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
@@ -377,14 +379,11 @@ def config4_side_object(device, n_prompts=512, reps=5):
 
 
 def _config4_fabric_bytes():
-    """Fabric-side bytes of one pass from the tracked PMC summary (per-launch FETCH_SIZE x 2 + WRITE_SIZE of the pass's
-    kernels at 512 rows, summed over the 22 + 2 dictionaries), or None."""
-    path = os.path.join(REPO, "profiles", "r02_config4_fabric_bytes.json")
+    """Fabric-side bytes of one pass from the tracked PMC summary (per-launch FETCH_SIZE x 2 + WRITE_SIZE of the five
+    kernels of the grouped pass at 512 rows x 24 dictionaries, tools/c4_pmc.sh + tools/c4_pmc_summary.py), or None."""
+    path = os.path.join(REPO, "profiles", "r03_config4_fabric_bytes.json")
     try:
-        k = json.load(open(path))["kernels"]
-        tot = lambda name: k[name]["fetch_bytes_per_launch"] + k[name]["write_bytes_per_launch"]  # noqa: E731
-        return {"bytes": 22 * tot("emit bf16 screen 128x128 tile (d_sae 24576)") + 2 * tot("emit bf16 screen 256x256 tile (d_sae 49152)")
-                + 26 * tot("sparse_finish_kernel<SCREENED>") + 24 * tot("convert_x_kernel"), "source": "profiles/r02_config4_fabric_bytes.json"}
+        return {"bytes": float(json.load(open(path))["pass_bytes"]), "source": "profiles/r03_config4_fabric_bytes.json"}
     except (OSError, KeyError, ValueError):
         return None
 
