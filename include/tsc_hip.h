@@ -95,7 +95,8 @@ int tsc_encode_dense_pre(const tsc_dict_t *dict, const float *x, int64_t M, floa
  * A "slot" is an independent partial list set; the encode kernel splits each batch's token tiles
  * over n_slots groups of workgroups so that no two workgroups ever touch one list, and
  * tsc_topk_finalize merges the slots.  tsc_topk_recommended_slots(d_sae) returns the slot count
- * that fills the chip evenly (any n_slots >= 1 is correct).
+ * that fills the chip evenly and -- 8 where that is possible -- keeps the W_enc slabs of the column tiles
+ * resident on one XCD within its L2 (any n_slots >= 1 is correct).
  * floor (optional, may be NULL): [d_sae] fp32 scratch.  When given and n_slots > 1, tsc_encode_topk first
  * writes each feature's current k-th best value over ALL slots into it and the encode kernel dismisses
  * candidates below it -- they cannot be in the merged result -- instead of only those below the k-th best

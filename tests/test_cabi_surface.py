@@ -42,8 +42,8 @@ def test_argument_errors_without_gpu():
     assert lib.tsc_dict_create(ctypes.byref(handle), 770, 24576, 768, 0, 16, 16, 16, None, None, None) == -3
     assert lib.tsc_encode_dense(None, None, 4, None, None) == -1
     assert lib.tsc_topk_recommended_slots(24576) == 8
-    assert lib.tsc_topk_recommended_slots(49152) == 4
-    assert lib.tsc_topk_recommended_slots(131072) == 1
+    assert lib.tsc_topk_recommended_slots(49152) == 8   # (4 also fills the chip; 8 keeps an XCD's W_enc slabs within its L2)
+    assert lib.tsc_topk_recommended_slots(131072) == 8
 
 
 def test_product_path_has_no_cpu_fallback():

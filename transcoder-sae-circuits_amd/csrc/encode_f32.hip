@@ -1004,9 +1004,16 @@ bool pick_large(int mode, const EncodeArgs &a) {
 
 // number of token-tile groups per column tile such that the grid is a whole number of waves of
 // resident workgroups (every workgroup does the same amount of work, so a ragged last wave of
-// workgroups is pure idle time)
+// workgroups is pure idle time).  Eight or more groups are tried first: the workgroups resident on an XCD are
+// consecutive in (column tile, group), so with s groups its 32 CUs hold 32/s column tiles -- at s = 8 their W_enc
+// slabs (4 x 393 KB bf16) stay in the XCD's 4-MiB L2 and every slab read after the first is an L2 hit, where one group
+// per column tile has 32 slabs (12.6 MB) thrashing it and re-reads every slab from the Infinity Cache per token tile
+// (measured, bf16 fused top-k at d_sae 131072 x 16384 tokens: 1.07 PFLOP/s with 1 group, 1.12 / 1.17 / 1.18 with
+// 2 / 4 / 8, 1.12 with 16; fp32 145.6 -> 147.2 TFLOP/s; tools/exp_slots.py).
 int balanced_split(int n_tiles_n, long long n_tiles_m, int resident, int cap) {
     if (cap > n_tiles_m) cap = (int)(n_tiles_m < 1 ? 1 : n_tiles_m);
+    for (int s = 8; s <= cap && s <= 16; ++s)
+        if (((long long)n_tiles_n * s) % resident == 0) return s;
     for (int s = 1; s <= cap; ++s)
         if (((long long)n_tiles_n * s) % resident == 0) return s;
     int s = (2 * resident + n_tiles_n - 1) / n_tiles_n;
