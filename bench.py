@@ -38,7 +38,7 @@ D_IN = 768
 PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
 PEAK_HBM_TBS = 8.0
 ZSAE_WIDE_LAYERS = (5, 7)
-TRAFFIC_PROFILES = ("profiles/r02_encode_topk_pmc.json", "profiles/r01_encode_topk_pmc_v9.json")
+TRAFFIC_PROFILES = ("profiles/r03_encode_topk_pmc.json", "profiles/r02_encode_topk_pmc.json", "profiles/r01_encode_topk_pmc_v9.json")
 
 
 def dictionary_widths():
