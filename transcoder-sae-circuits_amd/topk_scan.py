@@ -38,15 +38,29 @@ class HipTopkEngine:
         self.state = dictionary.new_topk_state(k)
         self.tokens_seen = 0
 
+    # While the lists are young a batch is fed in pieces no longer than what the lists have already seen: the screen's
+    # floor is the k-th best BEFORE a call, so a piece as long as the history has ~k candidates per feature above it, one
+    # three times as long ~3k -- each an exact recompute.  (65536-row batches: [16384 fp32][16384][32768], then whole.)
+    YOUNG_UNTIL_TOKENS = 131072
+
     def update(self, x: torch.Tensor, token_id_base: int) -> None:
         can_screen = self.screened and not self.bf16
-        cold = max(0, min(x.shape[0], self.SCREEN_AFTER_TOKENS - self.tokens_seen)) if can_screen else 0
-        if 0 < cold < x.shape[0]:  # a batch that straddles the warm-up: its head on the fp32 kernel, the rest screened
-            self.dictionary.encode_topk(x[:cold], token_id_base, self.state, bf16=False, screened=False)
-            self.dictionary.encode_topk(x[cold:], token_id_base + cold, self.state, bf16=False, screened=True)
-        else:
-            self.dictionary.encode_topk(x, token_id_base, self.state, bf16=self.bf16, screened=can_screen and cold == 0)
-        self.tokens_seen += x.shape[0]
+        n, done = x.shape[0], 0
+        if not can_screen:
+            self.dictionary.encode_topk(x, token_id_base, self.state, bf16=self.bf16, screened=False)
+            done = n
+        while done < n:
+            seen = self.tokens_seen + done
+            if seen < self.SCREEN_AFTER_TOKENS:  # the head of a sweep on the fp32 kernel (see above)
+                step, screened = min(n - done, self.SCREEN_AFTER_TOKENS - seen), False
+            elif seen < self.YOUNG_UNTIL_TOKENS:
+                step, screened = min(n - done, max(self.SCREEN_AFTER_TOKENS, seen)), True
+            else:
+                step, screened = n - done, True
+            piece = x if step == n else x[done:done + step]
+            self.dictionary.encode_topk(piece, token_id_base + done, self.state, bf16=False, screened=screened)
+            done += step
+        self.tokens_seen += n
 
     def finalize(self) -> Tuple[torch.Tensor, torch.Tensor]:
         return self.state.finalize()
@@ -55,7 +69,7 @@ class HipTopkEngine:
         """Resume from finalized lists (they become the running state)."""
         dev = self.state.device
         self.state.load(vals.to(dev, torch.float32), idx.to(dev, torch.int64))
-        self.tokens_seen = self.SCREEN_AFTER_TOKENS  # resumed lists are warm
+        self.tokens_seen = max(self.SCREEN_AFTER_TOKENS, self.YOUNG_UNTIL_TOKENS)  # resumed lists are warm
 
     @staticmethod
     def merge(vals: torch.Tensor, idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
