@@ -362,6 +362,14 @@ class _ResidualSpaceZ:
         return cur[1]
 
 
+def _residual_z(z_sae, w_o_flat: torch.Tensor) -> _ResidualSpaceZ:
+    """The z-SAE's residual-space view for this W_O (kept on the module: one fold per model, not per batch or lens)."""
+    adapter = z_sae.__dict__.get("_resid_adapter")
+    if adapter is None or not adapter.same_projection(w_o_flat):
+        adapter = _ResidualSpaceZ(z_sae, w_o_flat)
+        object.__setattr__(z_sae, "_resid_adapter", adapter)
+    return adapter
+
 _PASS_STREAMS: Dict[str, list] = {}
 
 
@@ -656,29 +664,34 @@ class CircuitLens:
 
             feat, val, count, recons, _, _ = self._ensure_pass()
             n_layers = self.model.cfg.n_layers
-            encs = []
-            for layer in range(n_layers):
-                encs += [self.z_saes[layer], self.mlp_transcoders[layer]]
-            handles = [e.device_dict() for e in encs]
             dev, cap, dm = feat.device, feat.shape[2], self.model.W_U.shape[0]
-            w_o = torch.stack([self._w_o_flat(l) for l in range(n_layers)])              # [L, n*d, d_model]
-            ok = all(h.d_out == handles[0].d_out for h in handles) and w_o.shape[1] == dm == handles[0].d_out
+            w_o = [self._w_o_flat(l) for l in range(n_layers)]                           # [n*d, d_model] per layer
+            ok = all(w.shape[1] == dm for w in w_o) and all(t.W_dec.shape[1] == dm for t in self.mlp_transcoders[:n_layers])
             st = {"ok": ok}
             if ok:
+                # every dictionary decodes into the residual stream (the z-SAEs through W_O, folded once: _ResidualSpaceZ),
+                # so a query meets ONE direction and does no W_O @ d product; what the auxiliary rows need of the z side
+                # -- z W_O and the z reconstructions through W_O -- is projected once per prompt
+                with torch.no_grad():
+                    z_views = [_residual_z(self.z_saes[l], w_o[l]) for l in range(n_layers)]
+                    handles = []
+                    for l in range(n_layers):
+                        handles += [z_views[l].device_dict(), self.mlp_transcoders[l].device_dict()]
+                    z_resid = [(self._dictionary_input("attn", l) @ w_o[l]).contiguous() for l in range(n_layers)]
+                    recon_resid = [(recons[2 * l] @ w_o[l]).contiguous() for l in range(n_layers)]
                 st.update(
-                    group=tsc_hip.ContribGroup(handles), w_o=w_o.contiguous(), n_layers=n_layers, cap=cap,
-                    d=torch.empty(dm, dtype=torch.float32, device=dev), dz=torch.empty(n_layers, dm, dtype=torch.float32, device=dev),
+                    group=tsc_hip.ContribGroup(handles), n_layers=n_layers, cap=cap,
+                    d=torch.empty(dm, dtype=torch.float32, device=dev),
                     scores=torch.empty(2 * n_layers, 1, cap, dtype=torch.float32, device=dev),
                     feat=torch.empty(2 * n_layers, 1, cap, dtype=torch.int32, device=dev),
                     count=torch.empty(2 * n_layers, 1, dtype=torch.int32, device=dev),
                     head=torch.empty(1, 2, dtype=torch.float32, device=dev),
                     aux=torch.empty(1, 5 * n_layers, dtype=torch.float32, device=dev),
                     b_o=torch.stack([self.model.b_O[l] for l in range(n_layers)]).contiguous(),
-                    z_b_dec=torch.stack([self.z_saes[l].b_dec.detach() for l in range(n_layers)]).contiguous(),
+                    z_b_out=[v.b_out for v in z_views],                                   # b_dec W_O
                     t_b_out=torch.stack([self.mlp_transcoders[l].b_dec_out.detach() for l in range(n_layers)]).contiguous(),
-                    z_in=[self._dictionary_input("attn", l) for l in range(n_layers)],  # kept: the tables point into them
+                    z_resid=z_resid, recon_resid=recon_resid, z_views=z_views,           # kept: the tables point into them
                     tables={}, tags={})
-                st["w_o2d"] = st["w_o"].reshape(n_layers * dm, dm)
                 names = ["scores", "feat", "count", "head", "aux"]
                 width = 2 + 5 * n_layers + 2 * n_layers * cap
                 if width > 15360:  # rows beyond tsc_lens_assemble's LDS are ranked out of its dense outputs
@@ -687,11 +700,9 @@ class CircuitLens:
                               mask=torch.empty(1, width, dtype=torch.bool, device=dev))
                     names += ["raw", "acts", "mask"]
                 st["query"] = tsc_hip.LensQuery(st["group"], feat, val, count, {n: st[n] for n in names}, [3, 2] * n_layers)
-                # per-dictionary directions: z-SAEs see W_O[layer] @ d (row l of dz), transcoders d itself
                 ptrs = st["group"].ds
-                for l in range(n_layers):
-                    ptrs[2 * l] = st["dz"].data_ptr() + 4 * dm * l
-                    ptrs[2 * l + 1] = st["d"].data_ptr()
+                for g in range(2 * n_layers):
+                    ptrs[g] = st["d"].data_ptr()
             self.__dict__["_fused"] = st
         return st
 
@@ -710,9 +721,9 @@ class CircuitLens:
     def _fused_lens(self, direction: torch.Tensor, seq_index: int, before: Optional[Tuple[str, int]], k: int):
         """``normalize_activations(vectors_before(kind, layer) @ direction)`` of position ``seq_index`` and its top-k as
         ``[(component, layer, feature, value)]`` -- the list ``ActiveFeatures.get_top_k_features`` returns, including its
-        stop at the first embed / pos_embed row -- in five launches and one device-to-host copy: ``W_O`` pull-back of the
-        direction, ``tsc_contrib_scores_many`` (every dictionary's active features at this position), ``tsc_rowdot_many``
-        (the auxiliary rows), ``tsc_lens_assemble`` over the dictionaries in front of the cut-off.  Returns None when the
+        stop at the first embed / pos_embed row -- in four launches and one device-to-host copy: the direction's copy,
+        ``tsc_contrib_scores_many`` (every dictionary's active features at this position, all in residual space),
+        ``tsc_rowdot_many`` (the auxiliary rows), ``tsc_lens_assemble`` over the dictionaries in front of the cut-off.  Returns None when the
         model's shapes rule the fused path out (the caller then takes the ``vectors`` path)."""
         import tsc_hip
 
@@ -727,21 +738,19 @@ class CircuitLens:
         out_cap = (max(1, max(counts[g][r] for g in range(n_groups))) + 63) // 64 * 64
         with torch.no_grad():
             st["d"].copy_(direction.reshape(-1))
-            torch.mv(st["w_o2d"], st["d"], out=st["dz"].view(-1))  # W_O[layer] @ d for every layer
             tab = st["tables"].get(seq_index)
             if tab is None:
                 dm = st["d"].shape[0]
                 tab = tsc_hip.RowDotTable(2 + 5 * n_layers, 1, dm)
                 row = lambda t: t.reshape(1, dm)  # noqa: E731
-                head, aux, d, dz = st["head"], st["aux"], st["d"], st["dz"]
+                head, aux, d = st["head"], st["aux"], st["d"]
                 tab.set(0, row(self.cache["embed"][0, seq_index]), None, d, head[:, 0])
                 tab.set(1, row(self.cache["pos_embed"][0, seq_index]), None, d, head[:, 1])
                 for l in range(n_layers):
                     j = 2 + 5 * l
-                    z_in = st["z_in"][l][seq_index]
                     tab.set(j, st["b_o"][l], None, d, aux[:, 5 * l])
-                    tab.set(j + 1, row(z_in), row(recons[2 * l][r]), dz[l], aux[:, 5 * l + 1])
-                    tab.set(j + 2, st["z_b_dec"][l], None, dz[l], aux[:, 5 * l + 2])
+                    tab.set(j + 1, row(st["z_resid"][l][seq_index]), row(st["recon_resid"][l][r]), d, aux[:, 5 * l + 1])
+                    tab.set(j + 2, st["z_b_out"][l], None, d, aux[:, 5 * l + 2])
                     tab.set(j + 3, row(self.cache["mlp_out", l][0, seq_index]), row(recons[2 * l + 1][r]), d, aux[:, 5 * l + 3])
                     tab.set(j + 4, st["t_b_out"][l], None, d, aux[:, 5 * l + 4])
                 st["tables"][seq_index] = tab
@@ -1129,12 +1138,7 @@ class BatchedCircuitLens:
             encs = []
             with torch.no_grad():
                 for layer in range(self.model.cfg.n_layers):
-                    z, w = self.z_saes[layer], self._w_o_flat(layer)
-                    adapter = z.__dict__.get("_resid_adapter")
-                    if adapter is None or not adapter.same_projection(w):
-                        adapter = _ResidualSpaceZ(z, w)
-                        object.__setattr__(z, "_resid_adapter", adapter)
-                    encs += [adapter, self.mlp_transcoders[layer]]
+                    encs += [_residual_z(self.z_saes[layer], self._w_o_flat(layer)), self.mlp_transcoders[layer]]
                 z_resid = torch.stack([xs[2 * l] @ self._w_o_flat(l) for l in range(self.model.cfg.n_layers)])
             self._resid = (encs, z_resid)
         return self._resid
