@@ -465,7 +465,16 @@ __device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
 #pragma unroll
                 for (int bm = 0; bm < WMB; ++bm)
 #pragma unroll
-                    for (int bn = 0; bn < WNB; ++bn)
+                    for (int bn = 0; bn < WNB; ++bn) {
+                        if (a.sq_entries) {
+                            // top-k screen: candidates are a few per million elements, so the lane's largest value of the
+                            // 32x32 block is tested first (15 v_max) and 16 compare-and-branch pairs are skipped; at the
+                            // lens pass's densities nearly every block has a candidate in some lane and the test is left out
+                            float mx = acc[bm][bn][0];
+#pragma unroll
+                            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[bm][bn][r]);
+                            if (!__builtin_amdgcn_ballot_w64(mx > thr_w[bn])) continue;
+                        }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const float v = acc[bm][bn][r];
@@ -483,6 +492,7 @@ __device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
                                 cnt += __builtin_popcountll(m);
                             }
                         }
+                    }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
