@@ -480,7 +480,9 @@ __device__ __forceinline__ void encode_body(const EncodeArgs &a, const int wg) {
                             const float v = acc[bm][bn][r];
                             const bool p = v > thr_w[bn];
                             const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
-                            if (m) {
+                            // (marked unlikely: hipcc then lays the no-candidate case out as the fall-through -- a taken
+                            // branch per element costs -- and moves the staging out of line; emit 680-690 -> 668 us)
+                            if (__builtin_expect(m != 0, 0)) {
                                 if (p) {
                                     const unsigned q = (unsigned)(cnt - win) +
                                                        __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
