@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void col_norm_kernel(const float *__restrict__
 // column for the bias both chains start from).  margin[n] = bound[0] wnorm[n] + bound[1] wnorm[N + n] + g |b_enc[n]|
 // bounds |exact pre-activation - screened pre-activation| of column n for every row.
 __global__ __launch_bounds__(256) void row_bound_kernel(const float *__restrict__ x, long long M, int K,
-                                                       const float *__restrict__ b_dec, float *__restrict__ bound) {
+                                                       const float *__restrict__ b_dec, float *__restrict__ bound,
+                                                       unsigned short *__restrict__ xt_out) {
     __shared__ float wave_max[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n_waves = (long long)gridDim.x * 4;
@@ -151,6 +152,11 @@ __global__ __launch_bounds__(256) void row_bound_kernel(const float *__restrict_
             const float4 v = xr[c], b = ((const float4 *)b_dec)[c];
             const float dx = v.x - b.x, dy = v.y - b.y, dz = v.z - b.z, dw = v.w - b.w;
             const float ex = rerr(dx), ey = rerr(dy), ez = rerr(dz), ew = rerr(dw);
+            if (xt_out) {  // the screen's x operand, rounded exactly as convert_x_kernel rounds it
+                union { unsigned short h[4]; uint2 v; } u;
+                u.h[0] = f32_to_bf16_rne(dx); u.h[1] = f32_to_bf16_rne(dy); u.h[2] = f32_to_bf16_rne(dz); u.h[3] = f32_to_bf16_rne(dw);
+                *(uint2 *)(xt_out + row * K + 4 * c) = u.v;
+            }
             sc += dx * dx + dy * dy + dz * dz + dw * dw;
             sd += ex * ex + ey * ey + ez * ez + ew * ew;
             sr += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
@@ -187,11 +193,14 @@ int tsc_launch_col_norms(const float *W, int K, int N, float *wnorm, hipStream_t
     return TSC_OK;
 }
 
-int tsc_launch_row_bound(const float *x, long long M, int K, const float *b_dec, float *bound, hipStream_t stream) {
+int tsc_launch_row_bound(const float *x, long long M, int K, const float *b_dec, float *bound, hipStream_t stream,
+                         void *xt_out) {
+    if (xt_out && M > TSC_BF16_WS_ROWS) return tsc_fail(TSC_ERR_UNSUPPORTED, "the bf16 staging buffer holds %d rows", (int)TSC_BF16_WS_ROWS);
     TSC_HIP_CHECK(hipMemsetAsync(bound, 0, 2 * sizeof(float), stream));  // the maxima; the per-row pairs are all written
     long long blocks = (M + 3) / 4;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(row_bound_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, M, K, b_dec, bound);
+    hipLaunchKernelGGL(row_bound_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, M, K, b_dec, bound,
+                       (unsigned short *)xt_out);
     TSC_HIP_CHECK(hipGetLastError());
     return TSC_OK;
 }
@@ -244,9 +253,11 @@ int tsc_launch_encode_bf16(int mode, const EncodeArgs &a, const void *W_bf16, vo
     for (long long r0 = 0; r0 < a.M; r0 += TSC_BF16_WS_ROWS) {
         const long long rows = a.M - r0 < TSC_BF16_WS_ROWS ? a.M - r0 : TSC_BF16_WS_ROWS;
         const long long n8 = rows * (a.K / 8);
-        hipLaunchKernelGGL(convert_x_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream,
-                           a.x + r0 * a.K, a.b_dec, n8, a.K / 8, (unsigned short *)x_bf16);
-        TSC_HIP_CHECK(hipGetLastError());
+        if (!(a.x_staged && a.M <= TSC_BF16_WS_ROWS)) {
+            hipLaunchKernelGGL(convert_x_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream,
+                               a.x + r0 * a.K, a.b_dec, n8, a.K / 8, (unsigned short *)x_bf16);
+            TSC_HIP_CHECK(hipGetLastError());
+        }
         EncodeArgs c = a;
         c.bf16 = 1;
         c.x = (const float *)x_bf16;

@@ -242,7 +242,8 @@ int tsc_launch_screen_topk(const tsc_dict *d, const float *x, long long M, long 
         float *bound = d->screen_bound;
         if (row_bound) bound = const_cast<float *>(row_bound);
         else {
-            int rc = tsc_launch_row_bound(xc, rows, d->d_in, d->b_dec, d->screen_bound, stream);
+            // (one pass over x: the row bounds and the screen's bf16 operand together)
+            int rc = tsc_launch_row_bound(xc, rows, d->d_in, d->b_dec, d->screen_bound, stream, d->x_bf16);
             if (rc) return rc;
         }
         TSC_HIP_CHECK(hipMemsetAsync(workspace, 0, 256 + counters_bytes, stream));
@@ -252,6 +253,7 @@ int tsc_launch_screen_topk(const tsc_dict *d, const float *x, long long M, long 
         a.M = rows; a.K = d->d_in; a.N = d->d_sae;
         a.m_split = n_slots;
         EncodeArgs s = a;  // K1: the screen
+        s.x_staged = row_bound ? 0 : 1;
         s.screen_wnorm = d->wnorm; s.screen_bound = bound;
         s.screen_rows = row_bound ? nullptr : bound + 2;  // the library's own bounds carry every row's pair
         s.sq_floor = floor; s.sq_entries = entries; s.sq_counters = counters; s.sq_overflow = overflow;

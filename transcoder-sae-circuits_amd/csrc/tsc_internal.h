@@ -39,6 +39,7 @@ struct EncodeArgs {
     const float *x, *W, *b_enc, *b_dec;
     const void *Wt;      // W_enc transposed, [N][K] (fp32, or bf16 when .bf16): the LDS-DMA kernels' W operand
     int bf16;            // x and Wt are the bf16 operands prepared by encode_operands.hip (see tsc_launch_encode_bf16)
+    int x_staged;        // tsc_launch_encode_bf16: the staging buffer already holds bf16(x - b_dec) of these rows (row_bound_kernel wrote it)
     const float *bias;   // b_enc - b_dec @ W_enc, or null: selects the LDS-DMA kernel when K % 64 == 0
     long long M;
     int K, N;
@@ -91,7 +92,9 @@ int tsc_launch_fold_bias(const float *W, const float *b_enc, const float *b_dec,
 int tsc_launch_encode_bf16(int mode, const EncodeArgs &a, const void *W_bf16, void *x_bf16, hipStream_t stream);
 int tsc_launch_col_norms(const float *W, int K, int N, float *wnorm, hipStream_t stream);
 // bound: 2 + 2 * M floats (maxima, then per-row pairs)
-int tsc_launch_row_bound(const float *x, long long M, int K, const float *b_dec, float *bound, hipStream_t stream);
+// xt_out (may be null): also store bf16(x - b_dec) [M][K] there, exactly what convert_x_kernel would (one pass over x instead of two)
+int tsc_launch_row_bound(const float *x, long long M, int K, const float *b_dec, float *bound, hipStream_t stream,
+                         void *xt_out = nullptr);
 size_t tsc_bf16_workspace_bytes(int K);
 int tsc_pack_w_bf16(const float *W, int K, int N, void *dst, hipStream_t stream);
 int tsc_transpose_w_f32(const float *W, int K, int N, float *dst, hipStream_t stream);
