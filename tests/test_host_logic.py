@@ -164,3 +164,43 @@ def test_token_sharded_sweep_two_ranks_gloo(tmp_path):
     for vals, idx in outs:  # every rank ends with the identical, complete answer
         assert np.array_equal(idx.numpy(), g["idx"].astype(np.int64))
         assert np.allclose(vals.numpy(), g["vals"], rtol=1e-4, atol=1e-5)
+
+
+def test_topk_engine_feeds_young_lists_in_pieces_no_longer_than_their_history():
+    """``HipTopkEngine.update`` (host logic only; a recording stand-in for the dictionary): the first 16384 rows of a sweep
+    go to the fp32 kernel, then -- while fewer than 131072 tokens have been seen -- a batch is fed to the screened top-k
+    in pieces no longer than what the lists have already seen (its floor is the k-th best BEFORE a call), then whole;
+    pieces tile the batch exactly, with consecutive token ids; an unscreened or bf16 engine passes batches through."""
+    import topk_scan
+
+    class Recorder:
+        def __init__(self):
+            self.calls = []
+
+        def new_topk_state(self, k):
+            return object()
+
+        def encode_topk(self, x, base, state, bf16=False, screened=False):
+            self.calls.append((x.shape[0], base, bf16, screened))
+
+    rec = Recorder()
+    eng = topk_scan.HipTopkEngine(rec, k=20)
+    x = torch.zeros(65536, 4)
+    eng.update(x, 1000)
+    assert rec.calls == [(16384, 1000, False, False), (16384, 1000 + 16384, False, True), (32768, 1000 + 32768, False, True)]
+    rec.calls.clear()
+    eng.update(x, 1000 + 65536)                      # 65536 seen: one piece as long as the history
+    eng.update(x[:50000], 1000 + 131072)             # 131072 seen: no longer young
+    assert rec.calls == [(65536, 66536, False, True), (50000, 132072, False, True)]
+    rec.calls.clear()
+    small = topk_scan.HipTopkEngine(rec, k=20)       # batches shorter than the fp32 head
+    for i in range(5):
+        small.update(x[:6000], 6000 * i)
+    assert [c[0] for c in rec.calls] == [6000, 6000, 4384, 1616, 6000, 6000]
+    assert [c[3] for c in rec.calls] == [False, False, False, True, True, True]
+    assert [c[1] for c in rec.calls] == [0, 6000, 12000, 16384, 18000, 24000]
+    rec.calls.clear()
+    for kwargs in ({"screened": False}, {"bf16": True}):
+        plain = topk_scan.HipTopkEngine(rec, k=20, **kwargs)
+        plain.update(x, 7)
+        assert rec.calls[-1] == (65536, 7, bool(kwargs.get("bf16")), False) and plain.tokens_seen == 65536
