@@ -204,3 +204,37 @@ def test_topk_engine_feeds_young_lists_in_pieces_no_longer_than_their_history():
         plain = topk_scan.HipTopkEngine(rec, k=20, **kwargs)
         plain.update(x, 7)
         assert rec.calls[-1] == (65536, 7, bool(kwargs.get("bf16")), False) and plain.tokens_seen == 65536
+
+
+def test_residual_space_z_folds_w_o_once_and_refolds_on_change():
+    """``circuit_lens._ResidualSpaceZ`` (host side, CPU tensors): ``W_dec W_O`` / ``b_dec W_O`` are folded once, reused while
+    nothing changed, and redone after an in-place update of the z-SAE's decoder or of W_O; ``same_projection`` accepts the
+    same storage or equal values (a model whose ``W_O`` property stacks a new tensor on every access) and nothing else."""
+    import circuit_lens
+
+    class Z(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(0)
+            self.W_enc = torch.nn.Parameter(torch.randn(12, 40, generator=g))
+            self.b_enc = torch.nn.Parameter(torch.randn(40, generator=g))
+            self.b_dec = torch.nn.Parameter(torch.randn(12, generator=g))
+            self.W_dec = torch.nn.Parameter(torch.randn(40, 12, generator=g))
+
+    z = Z()
+    w_o = torch.randn(12, 8, generator=torch.Generator().manual_seed(1))
+    view = circuit_lens._residual_z(z, w_o)
+    assert circuit_lens._residual_z(z, w_o) is view and circuit_lens._residual_z(z, w_o.clone()) is view
+    assert circuit_lens._residual_z(z, w_o * 2) is not view
+    view = circuit_lens._residual_z(z, w_o)
+    first = view.W_dec
+    assert view.W_dec is first and view.b_dec is z.b_dec
+    assert torch.allclose(first, z.W_dec.detach() @ w_o, atol=1e-6) and torch.allclose(view.b_out, z.b_dec.detach() @ w_o, atol=1e-6)
+    with torch.no_grad():
+        z.W_dec.mul_(2.0)
+    assert view.W_dec is not first and torch.allclose(view.W_dec, 2.0 * first, atol=1e-5)
+    second = view.W_dec
+    w_o.add_(1.0)
+    assert view.W_dec is not second and torch.allclose(view.W_dec, z.W_dec.detach() @ w_o, atol=1e-5)
+    import copy
+    assert "_resid_adapter" in z.__dict__ and isinstance(copy.deepcopy(z), Z)
